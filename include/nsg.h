@@ -1,0 +1,183 @@
+/*
+ * nsg.h -- C ABI of the MI355X-native batched NN evaluator for nshogi-engine.
+ *
+ * This is the drop-in boundary (DESIGN.md "Boundary").  Every entry point is
+ * `extern "C"`, takes plain pointers and sizes, and replaces one member of
+ * the reference's executor plugin interface; the reference file:line each one
+ * stands in for is cited next to it (paths under /root/reference/).
+ * The C++ adapter `nshogi::engine::infer::Hip` (include/nshogi_engine_amd/
+ * infer/hip.h) wraps this ABI behind the reference's `infer::Infer` virtuals
+ * so src/mcts and src/selfplay link unchanged.
+ *
+ * Threading contract (same as the reference): one evaluator
+ * per evaluation thread, at most one batch in flight per evaluator, not
+ * thread-safe per object, no global mutable state.  Results in the Dst*
+ * buffers are defined only after nsg_await() returns.
+ *
+ * All functions return NSG_OK (0) on success or a negative NSG_E_* code;
+ * nsg_last_error() returns a thread-local description of the last failure.
+ * There is NO CPU fallback: without a HIP device every compute entry fails.
+ */
+#ifndef NSG_H
+#define NSG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSG_OK 0
+#define NSG_E_INVALID (-1)   /* bad argument / wrong state                  */
+#define NSG_E_HIP (-2)       /* a HIP runtime call failed                   */
+#define NSG_E_IO (-3)        /* weight file could not be opened / read      */
+#define NSG_E_FORMAT (-4)    /* weight blob malformed or shape mismatch     */
+#define NSG_E_BUSY (-5)      /* a batch is already in flight                */
+#define NSG_E_NOT_LOADED (-6) /* compute called before nsg_load*            */
+
+#define NSG_NUM_SQUARES 81       /* core::NumSquares (trt.cc:60)            */
+#define NSG_MOVE_INDEX_MAX 2187  /* ml::MoveIndexMax = 27*81 (trt.cc:62,205) */
+#define NSG_BITBOARD_BYTES 16    /* sizeof(ml::FeatureBitboard)             */
+
+/* Arithmetic the trunk computes in.  fp32 = exact f32 MFMA
+ * (v_mfma_f32_16x16x4_f32); fp16/bf16 = 16-bit operands, f32 accumulate
+ * (v_mfma_f32_16x16x32_{f16,bf16}).  The reference enables TF32
+ * (trt.cc:161); gfx950 has no TF32 MFMA. */
+#define NSG_PRECISION_FP32 0
+#define NSG_PRECISION_FP16 1
+#define NSG_PRECISION_BF16 2
+
+typedef struct nsg_evaluator nsg_evaluator;
+
+/* Replaces infer::TensorRT::TensorRT(int GPUId, uint16_t BatchSizeMax,
+ * uint16_t NumChannels) -- src/infer/trt.h:44, src/infer/trt.cc:52-80:
+ * binds the device, allocates the device-side input/plane/output buffers
+ * sized for batch_size_max and creates one non-blocking stream. */
+int nsg_create(int gpu_id, int batch_size_max, int num_channels,
+               nsg_evaluator** out);
+
+/* Replaces infer::TensorRT::~TensorRT() -- src/infer/trt.cc:82-107. */
+int nsg_destroy(nsg_evaluator* ev);
+
+/* Selects the trunk arithmetic (NSG_PRECISION_*).  Must be called before
+ * nsg_load*; default NSG_PRECISION_FP32.  (The reference fixes this at
+ * engine-build time through BuilderFlag::kTF32, src/infer/trt.cc:160-161.) */
+int nsg_set_precision(nsg_evaluator* ev, int precision);
+
+/* Replaces infer::TensorRT::load(const std::string& Path, bool) --
+ * src/infer/trt.h:47, src/infer/trt.cc:109-232.  `path` names an NSGW v1
+ * weight file (DESIGN.md "Weight file"); BN is folded and the weights are
+ * re-laid into MFMA fragment order on upload.  The policy width is checked
+ * against NSG_MOVE_INDEX_MAX as trt.cc:193-210 does. */
+int nsg_load(nsg_evaluator* ev, const char* path);
+/* Same, from a host blob / from a device-resident blob (e.g. the buffer an
+ * RCCL broadcast just filled). */
+int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size);
+int nsg_load_device_blob(nsg_evaluator* ev, const void* device_blob,
+                         size_t size);
+
+/* Replaces infer::Infer::computeNonBlocking(const ml::FeatureBitboard*
+ * Features, std::size_t BatchSize, float* DstPolicy, float* DstWinRate,
+ * float* DstDrawRate) -- src/infer/infer.h:25-27, src/infer/trt.cc:234-272.
+ * `features` = batch * num_channels 16-byte feature bitboards (host memory,
+ * pinned or not); DstPolicy gets batch*2187 raw logits, DstWinRate/
+ * DstDrawRate batch floats in [0,1].  Returns after enqueueing H2D ->
+ * planes -> network -> 3x D2H on the evaluator's stream. */
+int nsg_compute_nonblocking(nsg_evaluator* ev, const void* features,
+                            size_t batch_size, float* dst_policy,
+                            float* dst_win_rate, float* dst_draw_rate);
+
+/* Replaces infer::Infer::computeBlocking -- src/infer/infer.h:28-30,
+ * src/infer/trt.cc:274-279. */
+int nsg_compute_blocking(nsg_evaluator* ev, const void* features,
+                         size_t batch_size, float* dst_policy,
+                         float* dst_win_rate, float* dst_draw_rate);
+
+/* Replaces infer::Infer::await() -- src/infer/infer.h:31, trt.cc:281-283
+ * (cudaStreamSynchronize). */
+int nsg_await(nsg_evaluator* ev);
+
+/* Replaces infer::Infer::isComputing() -- src/infer/infer.h:32,
+ * trt.cc:285-287 (cudaStreamQuery == cudaErrorNotReady).  Returns 1/0. */
+int nsg_is_computing(nsg_evaluator* ev);
+
+/* Replaces infer::TensorRT::resetGPU() -- src/infer/trt.h:57,
+ * trt.cc:289-291: re-binds the calling thread to the evaluator's device. */
+int nsg_reset_gpu(nsg_evaluator* ev);
+
+/* Replaces cuda::extractBits<ChannelsFirst>(float* Dest, const uint64_t*
+ * Src, int BatchSize, int NumChannels, cudaStream_t Stream) --
+ * src/cuda/extractbit.h:21-23, src/cuda/extractbit.cu:76-96.  dst/src are
+ * DEVICE pointers; `hip_stream` is a hipStream_t (NULL = default stream). */
+int nsg_extract_bits(float* dst, const uint64_t* src, int batch_size,
+                     int num_channels, int channels_first, void* hip_stream);
+
+/* Page-locking for the caller-owned host batch buffers; replaces the
+ * cudaHostRegister / cudaHostUnregister calls of evaluate::Evaluator --
+ * src/evaluate/evaluator.cc:94-105 and :110-115. */
+int nsg_host_register(void* ptr, size_t bytes);
+int nsg_host_unregister(void* ptr);
+
+/* ---- measurement hooks (no reference counterpart; used by bench.py and
+ * tests to time the device-resident path and to read intermediates) ---- */
+
+/* H2D of `batch_size` positions into the evaluator's device input buffer,
+ * synchronous. */
+int nsg_upload_features(nsg_evaluator* ev, const void* features,
+                        size_t batch_size);
+/* Enqueue planes + network on the already-resident input; outputs stay in
+ * the evaluator's device buffers.  No host transfer, no sync. */
+int nsg_forward_resident(nsg_evaluator* ev, size_t batch_size);
+/* D2H of the device output buffers, synchronous. */
+int nsg_download_outputs(nsg_evaluator* ev, size_t batch_size,
+                         float* dst_policy, float* dst_win_rate,
+                         float* dst_draw_rate);
+/* Debug read-back of the trunk output as fp32 [batch][F][81] (NCHW). */
+int nsg_download_trunk(nsg_evaluator* ev, size_t batch_size, float* dst);
+
+/* HIP-event timing of the dominant kernel (the F->F 3x3 residual
+ * convolution) on the evaluator's own stream.  While enabled, every forward
+ * brackets its run of trunk-conv launches with two events; nsg_profile_read
+ * synchronises and accumulates.  *launches counts kernel launches. */
+int nsg_profile_enable(nsg_evaluator* ev, int enable);
+int nsg_profile_read(nsg_evaluator* ev, double* trunk_ms_total,
+                     uint64_t* trunk_launches, double* forward_ms_total,
+                     uint64_t* forwards);
+
+typedef struct nsg_info {
+    int gpu_id;
+    int batch_size_max;
+    int num_channels;      /* input planes (86)                         */
+    int channels;          /* trunk width F                             */
+    int blocks;            /* residual blocks                           */
+    int value_channels;
+    int value_hidden;
+    int precision;         /* NSG_PRECISION_*                           */
+    int loaded;
+    int compute_units;     /* hipDeviceProp_t.multiProcessorCount       */
+    int clock_khz;         /* hipDeviceProp_t.clockRate                 */
+    uint64_t param_count;
+    double flops_per_position;       /* SURVEY.md 8d formula             */
+    double trunk_conv_flops_per_position; /* one F->F 3x3 conv: 2*81*9*F*F */
+    char device_name[128];
+} nsg_info;
+int nsg_get_info(nsg_evaluator* ev, nsg_info* info);
+
+/* CPU stand-in executors of the reference (src/infer/zero.cc, nothing.cc,
+ * random.cc): product code, selectable like EXECUTOR=zero|nothing|random
+ * (Makefile:107-121).  kind: 0 = Zero, 1 = Nothing, 2 = Random(seed). */
+typedef struct nsg_cpu_executor nsg_cpu_executor;
+int nsg_cpu_executor_create(int kind, uint64_t seed, nsg_cpu_executor** out);
+int nsg_cpu_executor_destroy(nsg_cpu_executor* ex);
+int nsg_cpu_executor_compute(nsg_cpu_executor* ex, const void* features,
+                             size_t batch_size, float* dst_policy,
+                             float* dst_win_rate, float* dst_draw_rate);
+
+const char* nsg_last_error(void);
+const char* nsg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSG_H */

@@ -1,0 +1,219 @@
+// extractbit.hip -- feature bitboards -> feature planes, gfx950.
+//
+// Replaces the reference's only GPU kernel, src/cuda/extractbit.cu
+// (K1 :15-39 NCHW, K2 :41-68 NHWC, launcher :76-96).  Same arithmetic per
+// output element:
+//   hi bit 24 = rotate-180 flag, hi bits 63..32 = f32 bit pattern of the
+//   plane's value, squares 0..62 = lo bits 0..62, squares 63..80 = hi bits
+//   0..17; out = bit(square') ? value : 0 with square' = rotate ? 80-sq : sq.
+// The result is an integer select of a bit pattern, so parity is bit-exact.
+//
+// The reference launches one 81-thread block per plane (B*C blocks, second
+// wave 17/64 occupied, every thread re-reading the same 16 bytes).  Here a
+// 256-thread workgroup stages a run of bitboards in LDS with one coalesced
+// 16-byte load per lane and then streams the planes out as fully coalesced
+// 16-byte stores; the kernel is HBM-write bound (29 240 B per position).
+#include "kernels.h"
+
+namespace nsg {
+namespace {
+
+__device__ __forceinline__ uint32_t selectBit(uint64_t lo, uint64_t hi, int bit) {
+    const uint32_t hi32 = (uint32_t)hi;
+    const int rotate = (hi32 >> 24) & 1;
+    const uint32_t value = (uint32_t)(hi >> 32);
+    const int target = rotate ? 80 - bit : bit;
+    const bool useHi = target >= 63;
+    const uint64_t word = useHi ? hi : lo;
+    const int shift = useHi ? target - 63 : target;
+    return ((word >> shift) & 1ULL) ? value : 0u;
+}
+
+constexpr int kThreads = 256;
+
+// ---- K1: NCHW.  One workgroup = kPlanes consecutive planes of the flat
+// [B*C] plane array = kPlanes*81 consecutive output dwords. ----
+constexpr int kPlanes = 64; // 64*81 = 5184 dwords = 1296 16-byte stores
+
+__global__ __launch_bounds__(kThreads) void extractNCHW(
+    uint32_t* __restrict__ dst, const uint4* __restrict__ src, int totalPlanes) {
+    __shared__ uint4 sPlanes[kPlanes];
+    const int plane0 = blockIdx.x * kPlanes;
+    const int nPlanes = min(kPlanes, totalPlanes - plane0);
+    if (threadIdx.x < nPlanes) {
+        sPlanes[threadIdx.x] = src[plane0 + threadIdx.x];
+    }
+    __syncthreads();
+
+    const int nDwords = nPlanes * 81;
+    uint32_t* out = dst + (size_t)plane0 * 81; // 16-byte aligned: 64*81*4
+    for (int q = threadIdx.x; q * 4 < nDwords; q += kThreads) {
+        const int e0 = q * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = e0 + i;
+            const int p = min(e / 81, nPlanes - 1);
+            const int bit = e - (e / 81) * 81;
+            const uint4 bb = sPlanes[p];
+            const uint64_t lo = ((uint64_t)bb.y << 32) | bb.x;
+            const uint64_t hi = ((uint64_t)bb.w << 32) | bb.z;
+            v[i] = selectBit(lo, hi, bit);
+        }
+        if (e0 + 4 <= nDwords) {
+            *reinterpret_cast<uint4*>(out + e0) = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int i = 0; e0 + i < nDwords; ++i) out[e0 + i] = v[i];
+        }
+    }
+}
+
+// ---- K2: NHWC, dst[(b*81 + sq)*C + c].  One workgroup per position. ----
+__global__ __launch_bounds__(kThreads) void extractNHWC(
+    uint32_t* __restrict__ dst, const uint4* __restrict__ src, int channels) {
+    extern __shared__ __attribute__((aligned(16))) uint4 sBoard[];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < channels; c += kThreads) {
+        sBoard[c] = src[(size_t)b * channels + c];
+    }
+    __syncthreads();
+    const int n = 81 * channels;
+    uint32_t* out = dst + (size_t)b * n;
+    for (int j = threadIdx.x; j < n; j += kThreads) {
+        const int sq = j / channels;
+        const int c = j - sq * channels;
+        const uint4 bb = sBoard[c];
+        const uint64_t lo = ((uint64_t)bb.y << 32) | bb.x;
+        const uint64_t hi = ((uint64_t)bb.w << 32) | bb.z;
+        out[j] = selectBit(lo, hi, sq);
+    }
+}
+
+// ---- trunk input: [b][sq][cpad] in the trunk's element type ----
+__device__ __forceinline__ uint16_t f32BitsToF16(uint32_t bits) {
+    const _Float16 h = (_Float16)__uint_as_float(bits);
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint16_t f32BitsToBf16(uint32_t bits) {
+    const __bf16 h = (__bf16)__uint_as_float(bits);
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+template <int PREC>
+__global__ __launch_bounds__(kThreads) void extractAct(
+    void* __restrict__ dstv, const uint4* __restrict__ src, int channels, int cpad) {
+    extern __shared__ __attribute__((aligned(16))) uint4 sBoard[];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < channels; c += kThreads) {
+        sBoard[c] = src[(size_t)b * channels + c];
+    }
+    __syncthreads();
+    const int quadsPerSq = cpad / 4;
+    const int nQuads = 81 * quadsPerSq;
+    for (int q = threadIdx.x; q < nQuads; q += kThreads) {
+        const int sq = q / quadsPerSq;
+        const int c0 = (q - sq * quadsPerSq) * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + i;
+            if (c < channels) {
+                const uint4 bb = sBoard[c];
+                const uint64_t lo = ((uint64_t)bb.y << 32) | bb.x;
+                const uint64_t hi = ((uint64_t)bb.w << 32) | bb.z;
+                v[i] = selectBit(lo, hi, sq);
+            } else {
+                v[i] = 0u;
+            }
+        }
+        const size_t e = ((size_t)b * 81 + sq) * cpad + c0;
+        if constexpr (PREC == kFp32) {
+            *reinterpret_cast<uint4*>((uint32_t*)dstv + e) =
+                make_uint4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (PREC == kFp16) {
+            uint2 o;
+            o.x = f32BitsToF16(v[0]) | ((uint32_t)f32BitsToF16(v[1]) << 16);
+            o.y = f32BitsToF16(v[2]) | ((uint32_t)f32BitsToF16(v[3]) << 16);
+            *reinterpret_cast<uint2*>((uint16_t*)dstv + e) = o;
+        } else {
+            uint2 o;
+            o.x = f32BitsToBf16(v[0]) | ((uint32_t)f32BitsToBf16(v[1]) << 16);
+            o.y = f32BitsToBf16(v[2]) | ((uint32_t)f32BitsToBf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>((uint16_t*)dstv + e) = o;
+        }
+    }
+}
+
+// activations [b][sq][c] T -> f32 [b][c][sq]   (debug read-back only)
+template <int PREC>
+__global__ void actToNCHW(const void* __restrict__ xv, float* __restrict__ dst, int c) {
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < 81 * c; j += blockDim.x) {
+        const int ch = j / 81;
+        const int sq = j - ch * 81;
+        const size_t e = ((size_t)b * 81 + sq) * c + ch;
+        float v;
+        if constexpr (PREC == kFp32) {
+            v = ((const float*)xv)[e];
+        } else if constexpr (PREC == kFp16) {
+            v = (float)((const _Float16*)xv)[e];
+        } else {
+            v = (float)((const __bf16*)xv)[e];
+        }
+        dst[(size_t)b * 81 * c + j] = v;
+    }
+}
+
+} // namespace
+
+hipError_t launchExtractBitsNCHW(float* dst, const uint64_t* src, int batch,
+                                 int channels, hipStream_t stream) {
+    const int total = batch * channels;
+    if (total <= 0) return hipErrorInvalidValue;
+    const int blocks = (total + kPlanes - 1) / kPlanes;
+    hipLaunchKernelGGL(extractNCHW, dim3(blocks), dim3(kThreads), 0, stream,
+                       (uint32_t*)dst, (const uint4*)src, total);
+    return hipGetLastError();
+}
+
+hipError_t launchExtractBitsNHWC(float* dst, const uint64_t* src, int batch,
+                                 int channels, hipStream_t stream) {
+    if (batch <= 0 || channels <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(extractNHWC, dim3(batch), dim3(kThreads),
+                       (size_t)channels * sizeof(uint4), stream, (uint32_t*)dst,
+                       (const uint4*)src, channels);
+    return hipGetLastError();
+}
+
+hipError_t launchExtractBitsAct(void* dst, const uint64_t* src, int batch,
+                                int channels, int cpad, int prec,
+                                hipStream_t stream) {
+    if (batch <= 0 || channels <= 0 || cpad % 4 != 0 || cpad < channels)
+        return hipErrorInvalidValue;
+    const size_t smem = (size_t)channels * sizeof(uint4);
+    if (prec == kFp32) {
+        hipLaunchKernelGGL(extractAct<kFp32>, dim3(batch), dim3(kThreads), smem,
+                           stream, dst, (const uint4*)src, channels, cpad);
+    } else if (prec == kFp16) {
+        hipLaunchKernelGGL(extractAct<kFp16>, dim3(batch), dim3(kThreads), smem,
+                           stream, dst, (const uint4*)src, channels, cpad);
+    } else {
+        hipLaunchKernelGGL(extractAct<kBf16>, dim3(batch), dim3(kThreads), smem,
+                           stream, dst, (const uint4*)src, channels, cpad);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launchActToNCHW(const void* x, float* dst, int batch, int c,
+                           int prec, hipStream_t stream) {
+    if (prec == kFp32) {
+        hipLaunchKernelGGL(actToNCHW<kFp32>, dim3(batch), dim3(256), 0, stream, x, dst, c);
+    } else if (prec == kFp16) {
+        hipLaunchKernelGGL(actToNCHW<kFp16>, dim3(batch), dim3(256), 0, stream, x, dst, c);
+    } else {
+        hipLaunchKernelGGL(actToNCHW<kBf16>, dim3(batch), dim3(256), 0, stream, x, dst, c);
+    }
+    return hipGetLastError();
+}
+
+} // namespace nsg

@@ -1,0 +1,432 @@
+// mfma_tile.h -- the MFMA tile kernel behind every contraction of the
+// policy/value/draw network on gfx950 (CDNA4).  Included by the three
+// per-precision translation units mfma_tile_{fp32,fp16,bf16}.hip.
+//
+// It is the body of the opaque TensorRT engine the reference enqueues at
+// src/infer/trt.cc:261 (F1 in SURVEY.md 2b; a7 in 8a).  Nothing here is
+// translated from the reference -- the reference contains no convolution or
+// GEMM code at all.
+//
+// GEMM view, per workgroup:   D^T[n][m] = sum_k W[k][n] * X[m][k]
+//   m = row (a board square, or a board for the value MLP)  -> MFMA column
+//   n = output channel                                       -> MFMA row
+// Three modes share the main loop:
+//   kConv : 3x3 "same" convolution over 9x9 boards, k = (tap, channel).
+//   kHeads: 1x1 convolutions of the policy head and the value-feature conv.
+//   kDense: plain rows x K GEMM (first layer of the value MLP).
+//
+// kConv design:
+// * Activations live in HBM as [board][square][channel] (channel innermost).
+//   A workgroup owns NB whole boards, so every 3x3 neighbour it needs is its
+//   own: no halo exchange, and the input tile is staged into LDS ONCE per
+//   128-byte channel chunk and then re-read by all nine taps (the 9x im2col
+//   blow-up never exists, not even in LDS).
+// * LDS image: [8 chunks of 16 B][entry], entry = 24 + b*110 + (y+1)*10 + x.
+//   Rows are 10 entries wide: the single zero entry x=9 is both the right
+//   halo of row y and the left halo of row y+1; rows y=-1 and y=9 are zero
+//   halo rows.  A tap is therefore a constant entry offset dy*10+dx with no
+//   bounds test, and because one chunk plane is a multiple of 256 B the
+//   ds_read_b128 of 16 consecutive entries is bank-conflict free.
+// * Every wave owns ALL rows of the tile and NFRAG*16 output channels, so
+//   activation fragments are shared through LDS while weight fragments are
+//   private to a wave: they stream straight from L2 into registers as 1-KiB
+//   fully coalesced wave loads (the host pre-packs them in lane order), two
+//   K-slabs ahead of use.
+// * The MFMA takes the weights as its A operand and the rows as its B
+//   operand, so a lane ends up holding 4 consecutive output channels of one
+//   row; the channel<->MFMA-row map is chosen at pack time so that a lane's
+//   NFRAG fragments form 4*NFRAG consecutive channels: the epilogue reads
+//   the residual and writes the result with wide row-contiguous vector
+//   accesses and no LDS transpose.
+//
+// Precisions: f32 operands -> v_mfma_f32_16x16x4_f32 (exact f32 FMA chain);
+// f16/bf16 operands -> v_mfma_f32_16x16x32_{f16,bf16}; accumulation is f32
+// in all cases.
+#ifndef NSG_MFMA_TILE_H
+#define NSG_MFMA_TILE_H
+
+#include "kernels.h"
+
+namespace nsg {
+namespace tile {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// native vector (not HIP's uint4 struct: struct copies lower to memcpy and
+// keep register arrays in scratch)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+enum Mode { kConv = 0, kHeads = 1, kDense = 2 };
+
+// SIZE = boards per workgroup (kConv) or 16-row fragments per workgroup.
+template <int MODE, int SIZE, int NWAVES>
+struct Geom {
+    static constexpr bool kBoards = (MODE == kConv);
+    static constexpr int kRows = kBoards ? SIZE * 81 : SIZE * 16;
+    static constexpr int kMF = (kRows + 15) / 16;
+    static constexpr int kEntries = kBoards ? SIZE * 110 + 24 : kMF * 16;
+    static constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
+    static constexpr int kBuf = 8 * kPlane;  // one 128-byte channel chunk
+    static constexpr int kLds = 2 * kBuf;    // double buffered
+    static constexpr int kLdsAlloc = kLds + 16; // + one trash slot for masked staging lanes
+    static constexpr int kThreads = NWAVES * 64;
+    static constexpr int kItems = (2 * kMF + NWAVES - 1) / NWAVES;
+    static constexpr int kTaps = kBoards ? 9 : 1;
+};
+
+template <bool BOARDS>
+__device__ __forceinline__ int entryOfRow(int m) {
+    if constexpr (BOARDS) {
+        const int b = m / 81;
+        const int sq = m - b * 81;
+        const int y = sq / 9;
+        const int x = sq - y * 9;
+        return 24 + b * 110 + (y + 1) * 10 + x;
+    } else {
+        return m;
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ void mfmaSlab(f32x4& acc, const u32x4& w, const u32x4& a) {
+    if constexpr (PREC == kFp32) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
+    } else if constexpr (PREC == kFp16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ uint16_t toBits16(float v) {
+    if constexpr (PREC == kFp16) {
+        return __builtin_bit_cast(uint16_t, (_Float16)v);
+    } else {
+        return __builtin_bit_cast(uint16_t, (__bf16)v);
+    }
+}
+template <int PREC>
+__device__ __forceinline__ uint32_t packPair(float lo, float hi) {
+    return (uint32_t)toBits16<PREC>(lo) | ((uint32_t)toBits16<PREC>(hi) << 16);
+}
+template <int PREC>
+__device__ __forceinline__ float unpackLo(uint32_t v) {
+    if constexpr (PREC == kFp16) {
+        return (float)__builtin_bit_cast(_Float16, (uint16_t)(v & 0xffffu));
+    } else {
+        return __uint_as_float(v << 16);
+    }
+}
+template <int PREC>
+__device__ __forceinline__ float unpackHi(uint32_t v) {
+    if constexpr (PREC == kFp16) {
+        return (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16));
+    } else {
+        return __uint_as_float(v & 0xffff0000u);
+    }
+}
+
+struct Args {
+    const unsigned char* x;   // rows x kdim, element type T
+    const u32x4* w;           // fragment-ordered weights
+    const float* bias;        // [cout]
+    const unsigned char* res; // kConv residual, same layout as y (or null)
+    unsigned char* y;         // kConv: rows x cout T;  kDense: rows x cout f32
+    float* policy;            // kHeads: [board][27*81] f32
+    unsigned char* vfeat;     // kHeads: [board][81*VC] T
+    int kdim;                 // input channels (multiple of the 128-byte chunk)
+    int cout;                 // output channels (multiple of 64)
+    int totalRows;            // valid rows (kHeads / kDense)
+    int relu;
+    int valueChannels;        // kHeads: channels [0,VC) = value conv, [VC,VC+27) = policy
+    int vfeatStride;          // kHeads: elements per board row of vfeat (>= 81*VC)
+};
+
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES>
+__global__ __launch_bounds__(NWAVES * 64, 1) void tileKernel(const Args A) {
+    using G = Geom<MODE, SIZE, NWAVES>;
+    constexpr int ES = (PREC == kFp32) ? 4 : 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15;
+    const int g = lane >> 4;
+    const size_t row0 = (size_t)blockIdx.x * G::kRows;
+    const int nkc = A.kdim * ES / 128;
+    const int nft = A.cout / 16;
+    const int waveGroup = blockIdx.y * NWAVES + wave; // group of NFRAG fragments
+    // kConv buffers are sized for whole workgroups; flat modes clamp rows.
+    const size_t lastRow = G::kBoards ? ~(size_t)0 : (size_t)(A.totalRows - 1);
+
+    if constexpr (G::kBoards) {
+        // zero the LDS image: halo entries stay zero for the whole kernel
+        for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
+            reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+
+    // per-lane LDS read bases of the row fragments
+    int abase[G::kMF];
+#pragma unroll
+    for (int f = 0; f < G::kMF; ++f) {
+        const int m = f * 16 + li;
+        if constexpr (G::kBoards) {
+            const int p = (m < G::kRows) ? entryOfRow<true>(m) : 11; // 11: every tap reads zeros
+            abase[f] = g * G::kPlane + (p - 11) * 16;
+        } else {
+            abase[f] = g * G::kPlane + m * 16;
+        }
+    }
+
+    // staging: item k of this wave moves 16 rows x 4 chunks (16 B per lane)
+    size_t srcOff[G::kItems];
+    int dstOff[G::kItems];
+    bool itemOk[G::kItems];
+#pragma unroll
+    for (int k = 0; k < G::kItems; ++k) {
+        const int wid = wave + k * NWAVES;
+        const int f = wid >> 1;
+        const int c = (wid & 1) * 4 + g;
+        const int m = f * 16 + li;
+        itemOk[k] = (wid < 2 * G::kMF) && (m < G::kRows);
+        const int mm = itemOk[k] ? m : 0;
+        size_t grow = row0 + mm;
+        if (grow > lastRow) grow = lastRow;
+        srcOff[k] = grow * (size_t)A.kdim * ES + c * 16;
+        // masked lanes store to the trash slot behind both buffers: the store
+        // stays unconditional, so st[] stays in registers
+        dstOff[k] = itemOk[k] ? c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16 : G::kLds;
+    }
+    u32x4 st[G::kItems];
+    // (macros, not lambdas: a by-reference capture keeps st[] in scratch)
+#define NSG_STAGE_LOAD(KC)                                                               \
+    _Pragma("unroll") for (int k = 0; k < G::kItems; ++k) {                              \
+        st[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)(KC) * 128);   \
+    }
+#define NSG_STAGE_WRITE(BUF)                                                             \
+    _Pragma("unroll") for (int k = 0; k < G::kItems; ++k) {                              \
+        *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? (BUF) * G::kBuf : 0) + dstOff[k]) = \
+            st[k];                                                                       \
+    }
+
+    // weight stream: slab q = (kc*taps + tap)*2 + s, NFRAG records per wave
+    const size_t slabStride = (size_t)nft * 64;
+    const u32x4* wp = A.w + (size_t)waveGroup * NFRAG * 64 + lane;
+    u32x4 w0[NFRAG], w1[NFRAG];
+#pragma unroll
+    for (int j = 0; j < NFRAG; ++j) {
+        w0[j] = wp[j * 64];
+        w1[j] = wp[slabStride + j * 64];
+    }
+    wp += 2 * slabStride;
+
+    f32x4 acc[G::kMF][NFRAG];
+#pragma unroll
+    for (int f = 0; f < G::kMF; ++f)
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    NSG_STAGE_LOAD(0)
+    if constexpr (G::kBoards) __syncthreads(); // zero fill done before staging writes
+    NSG_STAGE_WRITE(0)
+    __syncthreads();
+
+    constexpr int kTapUnroll = (PREC == kFp32) ? 1 : G::kTaps;
+    for (int kc = 0; kc < nkc; ++kc) {
+        // (the last iteration re-loads its own chunk: harmless, keeps st[] in registers)
+        NSG_STAGE_LOAD(kc + 1 < nkc ? kc + 1 : kc)
+        const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
+#pragma unroll kTapUnroll
+        for (int t = 0; t < G::kTaps; ++t) {
+            const int tapOff = G::kBoards ? ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16 : 0;
+            {
+                u32x4 a[G::kMF];
+#pragma unroll
+                for (int f = 0; f < G::kMF; ++f)
+                    a[f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + tapOff);
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+                    for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w0[j], a[f]);
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) w0[j] = wp[j * 64];
+            }
+            {
+                u32x4 a[G::kMF];
+#pragma unroll
+                for (int f = 0; f < G::kMF; ++f)
+                    a[f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + tapOff + 4 * G::kPlane);
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+                    for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w1[j], a[f]);
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) w1[j] = wp[slabStride + j * 64];
+            }
+            wp += 2 * slabStride;
+        }
+        NSG_STAGE_WRITE((kc + 1) & 1)
+        __syncthreads();
+    }
+
+#undef NSG_STAGE_LOAD
+#undef NSG_STAGE_WRITE
+
+    // ---- epilogue.  Lane (li, g) holds, for fragment j, channels
+    // cbase + 4j + {0..3} of row f*16 + li.
+    const int cbase = waveGroup * NFRAG * 16 + g * 4 * NFRAG;
+    float bv[NFRAG * 4];
+#pragma unroll
+    for (int i = 0; i < NFRAG * 4; ++i) bv[i] = A.bias[cbase + i];
+
+#pragma unroll
+    for (int f = 0; f < G::kMF; ++f) {
+        const int m = f * 16 + li;
+        const size_t grow = row0 + m;
+        const bool rowOk = G::kBoards ? (m < G::kRows) : (grow <= lastRow);
+        if (!rowOk) continue;
+        float v[NFRAG * 4];
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[f][j][r] + bv[j * 4 + r];
+
+        if constexpr (MODE == kConv) {
+            const size_t e = (grow * (size_t)A.cout + cbase) * ES;
+            if constexpr (HAS_RES) {
+                if constexpr (PREC == kFp32) {
+#pragma unroll
+                    for (int j = 0; j < NFRAG; ++j) {
+                        const f32x4 rr = *reinterpret_cast<const f32x4*>(A.res + e + j * 16);
+                        v[j * 4 + 0] += rr.x; v[j * 4 + 1] += rr.y;
+                        v[j * 4 + 2] += rr.z; v[j * 4 + 3] += rr.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NFRAG; ++j) {
+                        const u32x2 rr = *reinterpret_cast<const u32x2*>(A.res + e + j * 8);
+                        v[j * 4 + 0] += unpackLo<PREC>(rr.x); v[j * 4 + 1] += unpackHi<PREC>(rr.x);
+                        v[j * 4 + 2] += unpackLo<PREC>(rr.y); v[j * 4 + 3] += unpackHi<PREC>(rr.y);
+                    }
+                }
+            }
+            if (A.relu) {
+#pragma unroll
+                for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            if constexpr (PREC == kFp32) {
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j)
+                    *reinterpret_cast<f32x4*>(A.y + e + j * 16) =
+                        f32x4{v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
+            } else if constexpr (NFRAG % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < NFRAG; j += 2)
+                    *reinterpret_cast<u32x4*>(A.y + e + j * 8) = u32x4{
+                        packPair<PREC>(v[j * 4], v[j * 4 + 1]), packPair<PREC>(v[j * 4 + 2], v[j * 4 + 3]),
+                        packPair<PREC>(v[j * 4 + 4], v[j * 4 + 5]), packPair<PREC>(v[j * 4 + 6], v[j * 4 + 7])};
+            } else {
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j)
+                    *reinterpret_cast<u32x2*>(A.y + e + j * 8) = u32x2{
+                        packPair<PREC>(v[j * 4], v[j * 4 + 1]), packPair<PREC>(v[j * 4 + 2], v[j * 4 + 3])};
+            }
+        } else if constexpr (MODE == kHeads) {
+            const int b = (int)(grow / 81);
+            const int sq = (int)(grow - (size_t)b * 81);
+            const int vc = A.valueChannels;
+#pragma unroll
+            for (int i = 0; i < NFRAG * 4; ++i) {
+                const int n = cbase + i;
+                if (n < vc) {
+                    const float r = fmaxf(v[i], 0.f);
+                    const size_t e = (size_t)b * A.vfeatStride + (size_t)sq * vc + n;
+                    if constexpr (PREC == kFp32) {
+                        reinterpret_cast<float*>(A.vfeat)[e] = r;
+                    } else {
+                        reinterpret_cast<uint16_t*>(A.vfeat)[e] = toBits16<PREC>(r);
+                    }
+                } else if (n < vc + 27) {
+                    A.policy[(size_t)b * 2187 + (size_t)(n - vc) * 81 + sq] = v[i];
+                }
+            }
+        } else { // kDense: f32 output, bias + optional ReLU
+            if (A.relu) {
+#pragma unroll
+                for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            float* out = reinterpret_cast<float*>(A.y) + grow * (size_t)A.cout + cbase;
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j)
+                *reinterpret_cast<f32x4*>(out + j * 4) =
+                    f32x4{v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
+        }
+    }
+}
+
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES>
+hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
+    using G = Geom<MODE, SIZE, NWAVES>;
+    const int gy = a.cout / (NWAVES * NFRAG * 16);
+    if (gy < 1 || gy * NWAVES * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
+    hipError_t err;
+    if (MODE == kConv && a.res) {
+        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, (MODE == kConv)>;
+        err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a);
+    } else {
+        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false>;
+        err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a);
+    }
+    return hipGetLastError();
+}
+
+// Per-precision entry points (one translation unit each).
+template <int PREC>
+hipError_t launchConvPrec(const Args& a, int batch, const ConvPlan& p, hipStream_t stream) {
+    const int gx = (batch + p.nb - 1) / p.nb;
+#define NSG_CASE(NB_, NW_) \
+    if (p.nb == NB_ && p.nfrag == 4 && p.nwaves == NW_) return launchOne<PREC, kConv, NB_, 4, NW_>(a, gx, stream);
+    NSG_CASE(2, 4) NSG_CASE(2, 3) NSG_CASE(2, 2) NSG_CASE(2, 1)
+    NSG_CASE(1, 4) NSG_CASE(1, 3) NSG_CASE(1, 2) NSG_CASE(1, 1)
+#undef NSG_CASE
+    return hipErrorInvalidValue;
+}
+template <int PREC>
+hipError_t launchHeadsPrec(const Args& a, hipStream_t stream) {
+    constexpr int kMF = 8; // 128 rows per workgroup
+    const int gx = (a.totalRows + kMF * 16 - 1) / (kMF * 16);
+    return launchOne<PREC, kHeads, kMF, 4, 1>(a, gx, stream);
+}
+template <int PREC>
+hipError_t launchDensePrec(const Args& a, hipStream_t stream) {
+    constexpr int kMF = 2; // 32 rows per workgroup
+    const int gx = (a.totalRows + kMF * 16 - 1) / (kMF * 16);
+    return launchOne<PREC, kDense, kMF, 4, 1>(a, gx, stream);
+}
+
+hipError_t launchConvFp32(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchConvFp16(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchConvBf16(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchHeadsFp32(const Args& a, hipStream_t s);
+hipError_t launchHeadsFp16(const Args& a, hipStream_t s);
+hipError_t launchHeadsBf16(const Args& a, hipStream_t s);
+hipError_t launchDenseFp32(const Args& a, hipStream_t s);
+hipError_t launchDenseFp16(const Args& a, hipStream_t s);
+hipError_t launchDenseBf16(const Args& a, hipStream_t s);
+
+} // namespace tile
+} // namespace nsg
+
+#endif

@@ -1,0 +1,197 @@
+// tile_launch.hip -- host side of the MFMA tile kernels: tile-plan choice,
+// precision dispatch, weight packing, and the small value-output kernel.
+#include "mfma_tile.h"
+
+#include <string.h>
+
+namespace nsg {
+
+ConvPlan chooseConvPlan(int batch, int cout, int computeUnits) {
+    ConvPlan p;
+    p.nfrag = kNfrag;
+    const int groups = cout / (kNfrag * 16); // 64-channel wave groups
+    // Widest workgroup that divides the channel groups: all its waves share
+    // one LDS image of the input tile.
+    p.nwaves = (groups % 4 == 0) ? 4 : (groups % 3 == 0) ? 3 : (groups % 2 == 0) ? 2 : 1;
+    // Two boards per workgroup waste less of the last 16-row fragment
+    // (162 -> 176 rows vs 81 -> 96) but halve the grid: use them once the
+    // grid still covers most of the chip.
+    const int wgs2 = ((batch + 1) / 2) * (groups / p.nwaves);
+    p.nb = (wgs2 * 4 >= computeUnits * 3) ? 2 : 1;
+    return p;
+}
+
+hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
+                         const void* residual, void* y, int batch, int cin,
+                         int cout, int relu, int prec, const ConvPlan& plan,
+                         hipStream_t stream) {
+    if (batch <= 0 || (cin * elemSize(prec)) % 128 != 0 || cout % 64 != 0)
+        return hipErrorInvalidValue;
+    tile::Args a{};
+    a.x = (const unsigned char*)x;
+    a.w = (const tile::u32x4*)wfrag;
+    a.bias = bias;
+    a.res = (const unsigned char*)residual;
+    a.y = (unsigned char*)y;
+    a.kdim = cin;
+    a.cout = cout;
+    a.totalRows = batch * 81;
+    a.relu = relu;
+    switch (prec) {
+    case kFp32: return tile::launchConvFp32(a, batch, plan, stream);
+    case kFp16: return tile::launchConvFp16(a, batch, plan, stream);
+    case kBf16: return tile::launchConvBf16(a, batch, plan, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launchHeads(const void* x, const void* wfrag, const float* bias,
+                       float* policy, void* vfeat, int batch, int channels,
+                       int coutPadded, int valueChannels, int vfeatStride,
+                       int prec, hipStream_t stream) {
+    if (batch <= 0 || (channels * elemSize(prec)) % 128 != 0 || coutPadded % 64 != 0 ||
+        valueChannels + 27 > coutPadded || vfeatStride < 81 * valueChannels)
+        return hipErrorInvalidValue;
+    tile::Args a{};
+    a.x = (const unsigned char*)x;
+    a.w = (const tile::u32x4*)wfrag;
+    a.bias = bias;
+    a.policy = policy;
+    a.vfeat = (unsigned char*)vfeat;
+    a.kdim = channels;
+    a.cout = coutPadded;
+    a.totalRows = batch * 81;
+    a.valueChannels = valueChannels;
+    a.vfeatStride = vfeatStride;
+    switch (prec) {
+    case kFp32: return tile::launchHeadsFp32(a, stream);
+    case kFp16: return tile::launchHeadsFp16(a, stream);
+    case kBf16: return tile::launchHeadsBf16(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launchDense(const void* x, const void* wfrag, const float* bias,
+                       float* y, int rows, int kdim, int cout, int relu,
+                       int prec, hipStream_t stream) {
+    if (rows <= 0 || (kdim * elemSize(prec)) % 128 != 0 || cout % 64 != 0)
+        return hipErrorInvalidValue;
+    tile::Args a{};
+    a.x = (const unsigned char*)x;
+    a.w = (const tile::u32x4*)wfrag;
+    a.bias = bias;
+    a.y = (unsigned char*)y;
+    a.kdim = kdim;
+    a.cout = cout;
+    a.totalRows = rows;
+    a.relu = relu;
+    switch (prec) {
+    case kFp32: return tile::launchDenseFp32(a, stream);
+    case kFp16: return tile::launchDenseFp16(a, stream);
+    case kBf16: return tile::launchDenseBf16(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// Value MLP layer 2: one wave per board, 64-lane shuffle reduction.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void valueOutKernel(
+    const float* __restrict__ h, const float* __restrict__ w2,
+    const float* __restrict__ b2, float* __restrict__ value,
+    float* __restrict__ draw, int batch, int hidden) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int j = lane; j < hidden; j += 64) {
+        const float hv = h[(size_t)b * hidden + j];
+        s0 = fmaf(hv, w2[j], s0);
+        s1 = fmaf(hv, w2[hidden + j], s1);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off);
+        s1 += __shfl_xor(s1, off);
+    }
+    if (lane == 0) {
+        const float o0 = s0 + b2[0];
+        const float o1 = s1 + b2[1];
+        value[b] = 0.5f * (tanhf(o0) + 1.0f);
+        draw[b] = 1.0f / (1.0f + expf(-o1));
+    }
+}
+} // namespace
+
+hipError_t launchValueOut(const float* h, const float* w2, const float* b2,
+                          float* value, float* draw, int batch, int hidden,
+                          hipStream_t stream) {
+    if (batch <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(valueOutKernel, dim3((batch + 3) / 4), dim3(256), 0, stream,
+                       h, w2, b2, value, draw, batch, hidden);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Host-side weight packing.  Record (q, nf, lane) holds, for MFMA row
+// rho = lane & 15 and lane group g = lane >> 4 of output fragment nf:
+//   out channel n = (nf / 4) * 64 + (rho >> 2) * 16 + (nf % 4) * 4 + (rho & 3)
+//   slab        q = (kc*taps + tap)*2 + s
+//   f32 : 4 values, input channel kc*32 + s*16 + 4*g + i          (i = 0..3)
+//   16b : 8 values, input channel kc*64 + s*32 + 8*g + i          (i = 0..7)
+// Two zero slabs are appended so the kernel's two-slab-ahead prefetch never
+// reads past the allocation.
+// ---------------------------------------------------------------------------
+static inline uint16_t hostF32ToF16(float f) {
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+static inline uint16_t hostF32ToBf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40); // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u); // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+size_t tileWeightRecords(int taps, int kdim, int cout, int prec) {
+    const int nkc = kdim / chunkChannels(prec);
+    return ((size_t)nkc * taps * 2 + 2) * (cout / 16) * 64;
+}
+
+void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
+                     int kdim, int cout, int prec, void* dst) {
+    const int kcCh = chunkChannels(prec);
+    const int nkc = kdim / kcCh;
+    const int nft = cout / 16;
+    const int per = (prec == kFp32) ? 4 : 8; // values per record
+    unsigned char* out = (unsigned char*)dst;
+    memset(out, 0, tileWeightRecords(taps, kdim, cout, prec) * 16);
+    for (int c = 0; c < nkc; ++c)
+        for (int t = 0; t < taps; ++t)
+            for (int s = 0; s < 2; ++s) {
+                const size_t q = ((size_t)c * taps + t) * 2 + s;
+                for (int nf = 0; nf < nft; ++nf)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int rho = lane & 15, g = lane >> 4;
+                        const int n = (nf / kNfrag) * kNfrag * 16 + (rho >> 2) * 4 * kNfrag +
+                                      (nf % kNfrag) * 4 + (rho & 3);
+                        unsigned char* rec = out + ((q * nft + nf) * 64 + lane) * 16;
+                        for (int i = 0; i < per; ++i) {
+                            const int k = c * kcCh + s * (kcCh / 2) + per * g + i;
+                            const float v = (k < kReal) ? get(ctx, n, k, t) : 0.f;
+                            if (prec == kFp32) {
+                                memcpy(rec + i * 4, &v, 4);
+                            } else {
+                                const uint16_t hb = (prec == kFp16) ? hostF32ToF16(v) : hostF32ToBf16(v);
+                                memcpy(rec + i * 2, &hb, 2);
+                            }
+                        }
+                    }
+            }
+}
+
+} // namespace nsg

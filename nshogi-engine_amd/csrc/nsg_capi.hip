@@ -1,0 +1,675 @@
+// nsg_capi.hip -- implementation of the C ABI declared in include/nsg.h.
+//
+// One nsg_evaluator = one (device, stream) executor, the role the reference
+// gives to infer::TensorRT (src/infer/trt.h:42-88, src/infer/trt.cc).  The
+// forward pass it enqueues replaces trt.cc:234-272:
+//     H2D bitboards -> feature planes -> policy/value/draw network -> 3x D2H
+// all on the evaluator's own non-blocking stream.  No CPU fallback exists:
+// every compute entry fails with NSG_E_HIP when no device is usable.
+#include "../../include/nsg.h"
+#include "kernels/kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string gLastError;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    gLastError = buf;
+    return code;
+}
+
+#define NSG_HIP(call)                                                             \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            return fail(NSG_E_HIP, "%s failed: %s (%s:%d)", #call,                \
+                        hipGetErrorString(e_), __FILE__, __LINE__);               \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n, bool zero) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(NSG_E_HIP, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+        }
+        bytes = n;
+        if (zero) {
+            e = hipMemset(p, 0, n);
+            if (e != hipSuccess) return fail(NSG_E_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+        }
+        return NSG_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct ConvLayer {
+    DevBuf w;    // fragment-ordered weights
+    DevBuf bias; // f32 [cout]
+    int cin = 0; // padded input channels
+};
+
+// Parsed view of an NSGW v1 blob (DESIGN.md "Weight file").
+struct NetView {
+    int cin, F, blocks, pc, vc, vh;
+    float eps;
+    const float* stemW; const float* stemBn;
+    std::vector<const float*> w1, bn1, w2, bn2;
+    const float* polW; const float* polB;
+    const float* valW; const float* valBn;
+    const float* fc1W; const float* fc1B;
+    const float* fc2W; const float* fc2B;
+    uint64_t params;
+};
+
+int parseBlob(const void* blob, size_t size, NetView* nv) {
+    if (size < 64) return fail(NSG_E_FORMAT, "weight blob too small (%zu bytes)", size);
+    const unsigned char* p = (const unsigned char*)blob;
+    if (memcmp(p, "NSGW", 4) != 0) return fail(NSG_E_FORMAT, "bad magic (not an NSGW file)");
+    uint32_t h[15];
+    memcpy(h, p + 4, sizeof(h));
+    if (h[0] != 1) return fail(NSG_E_FORMAT, "unsupported NSGW version %u", h[0]);
+    nv->cin = (int)h[1]; nv->F = (int)h[2]; nv->blocks = (int)h[3];
+    nv->pc = (int)h[4]; nv->vc = (int)h[5]; nv->vh = (int)h[6];
+    memcpy(&nv->eps, &h[7], 4);
+    const size_t F = nv->F, C = nv->cin, VC = nv->vc, VH = nv->vh, PC = nv->pc;
+    if (F == 0 || C == 0 || VC == 0 || VH == 0 || PC == 0 || nv->blocks < 0)
+        return fail(NSG_E_FORMAT, "zero dimension in NSGW header");
+    const size_t need = F * C * 9 + 4 * F + (size_t)nv->blocks * 2 * (F * F * 9 + 4 * F) +
+                        PC * F + PC + VC * F + 4 * VC + VH * VC * 81 + VH + 2 * VH + 2;
+    if (size != 64 + need * sizeof(float))
+        return fail(NSG_E_FORMAT, "NSGW size mismatch: have %zu, header implies %zu", size,
+                    64 + need * sizeof(float));
+    nv->params = need;
+    const float* f = (const float*)(p + 64);
+    nv->stemW = f; f += F * C * 9;
+    nv->stemBn = f; f += 4 * F;
+    nv->w1.resize(nv->blocks); nv->bn1.resize(nv->blocks);
+    nv->w2.resize(nv->blocks); nv->bn2.resize(nv->blocks);
+    for (int k = 0; k < nv->blocks; ++k) {
+        nv->w1[k] = f; f += F * F * 9;
+        nv->bn1[k] = f; f += 4 * F;
+        nv->w2[k] = f; f += F * F * 9;
+        nv->bn2[k] = f; f += 4 * F;
+    }
+    nv->polW = f; f += PC * F;
+    nv->polB = f; f += PC;
+    nv->valW = f; f += VC * F;
+    nv->valBn = f; f += 4 * VC;
+    nv->fc1W = f; f += VH * VC * 81;
+    nv->fc1B = f; f += VH;
+    nv->fc2W = f; f += 2 * VH;
+    nv->fc2B = f; f += 2;
+    return NSG_OK;
+}
+
+// BN folding in double: w' = w * g/sqrt(v+eps), b' = beta - mean * g/sqrt(v+eps)
+void foldBn(const float* bn, int n, float eps, std::vector<double>* scale, std::vector<float>* bias) {
+    scale->resize(n);
+    bias->resize(n);
+    for (int i = 0; i < n; ++i) {
+        const double g = bn[0 * n + i], b = bn[1 * n + i], m = bn[2 * n + i], v = bn[3 * n + i];
+        const double s = g / std::sqrt(v + (double)eps);
+        (*scale)[i] = s;
+        (*bias)[i] = (float)(b - m * s);
+    }
+}
+
+struct Conv3Ctx { const float* w; const double* scale; int cin; };
+float conv3Get(const void* c, int n, int k, int tap) {
+    const Conv3Ctx* x = (const Conv3Ctx*)c;
+    return (float)((double)x->w[((size_t)n * x->cin + k) * 9 + tap] * x->scale[n]);
+}
+struct HeadsCtx { const float* valW; const double* valScale; const float* polW; int F, vc, pc; };
+float headsGet(const void* c, int n, int k, int) {
+    const HeadsCtx* x = (const HeadsCtx*)c;
+    if (n < x->vc) return (float)((double)x->valW[(size_t)n * x->F + k] * x->valScale[n]);
+    if (n < x->vc + x->pc) return x->polW[(size_t)(n - x->vc) * x->F + k];
+    return 0.f;
+}
+struct Fc1Ctx { const float* w; int vc; };
+float fc1Get(const void* c, int n, int k, int) {
+    const Fc1Ctx* x = (const Fc1Ctx*)c;
+    const int sq = k / x->vc, ch = k - sq * x->vc; // device K index = sq*VC + c
+    return x->w[(size_t)n * x->vc * 81 + (size_t)ch * 81 + sq];
+}
+
+constexpr int kMaxEventPairs = 1024;
+
+} // namespace
+
+struct nsg_evaluator {
+    int gpu = 0;
+    int batchMax = 0;
+    int numChannels = 0;
+    int prec = NSG_PRECISION_FP32;
+    bool loaded = false;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+
+    // network dims
+    int F = 0, blocks = 0, vc = 0, vh = 0, cpad = 0, headsCout = 0, fc1K = 0;
+    uint64_t params = 0;
+
+    // device buffers (sized for batchMax rounded up to whole workgroups)
+    DevBuf input;         // bitboards  [B][C][16 B]          (trt.cc:57-58)
+    DevBuf planes;        // trunk input [Bpad][81][cpad] T   (trt.cc:59-60, other layout)
+    DevBuf act[3];        // trunk activations [Bpad][81][F] T
+    DevBuf policy;        // [B][2187] f32                    (trt.cc:61-62)
+    DevBuf value, draw;   // [B] f32                          (trt.cc:63-66)
+    DevBuf vfeat;         // [B][fc1K] T
+    DevBuf hidden;        // [B][VH] f32
+    DevBuf scratch;       // debug read-back
+
+    ConvLayer stem;
+    std::vector<ConvLayer> conv1, conv2;
+    ConvLayer heads;
+    ConvLayer fc1;
+    DevBuf fc2W, fc2B;
+
+    void* trunkOut = nullptr; // which act[] holds the trunk output of the last forward
+
+    // profiling
+    bool profile = false;
+    std::vector<hipEvent_t> ev; // 4 per forward: fwd begin, trunk begin, trunk end, fwd end
+    int evUsed = 0;
+    double trunkMs = 0, fwdMs = 0;
+    uint64_t trunkLaunches = 0, forwards = 0;
+    int pendingTrunkLaunchesPerFwd = 0;
+};
+
+namespace {
+
+int bind(nsg_evaluator* ev) {
+    NSG_HIP(hipSetDevice(ev->gpu));
+    return NSG_OK;
+}
+
+int drainProfile(nsg_evaluator* ev) {
+    if (ev->evUsed == 0) return NSG_OK;
+    NSG_HIP(hipStreamSynchronize(ev->stream));
+    for (int i = 0; i < ev->evUsed; i += 4) {
+        float a = 0, b = 0;
+        NSG_HIP(hipEventElapsedTime(&a, ev->ev[i + 1], ev->ev[i + 2]));
+        NSG_HIP(hipEventElapsedTime(&b, ev->ev[i + 0], ev->ev[i + 3]));
+        ev->trunkMs += a;
+        ev->fwdMs += b;
+        ev->trunkLaunches += (uint64_t)ev->pendingTrunkLaunchesPerFwd;
+        ev->forwards += 1;
+    }
+    ev->evUsed = 0;
+    return NSG_OK;
+}
+
+int uploadLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int kdim,
+                int cout, int prec, const std::vector<float>& bias, ConvLayer* L) {
+    const size_t bytes = nsg::tileWeightRecords(taps, kdim, cout, prec) * 16;
+    std::vector<unsigned char> host(bytes);
+    nsg::packTileWeights(get, ctx, taps, kReal, kdim, cout, prec, host.data());
+    int rc = L->w.alloc(bytes, false);
+    if (rc) return rc;
+    NSG_HIP(hipMemcpy(L->w.p, host.data(), bytes, hipMemcpyHostToDevice));
+    std::vector<float> b(cout, 0.f);
+    for (size_t i = 0; i < bias.size() && i < (size_t)cout; ++i) b[i] = bias[i];
+    rc = L->bias.alloc((size_t)cout * 4, false);
+    if (rc) return rc;
+    NSG_HIP(hipMemcpy(L->bias.p, b.data(), (size_t)cout * 4, hipMemcpyHostToDevice));
+    L->cin = kdim;
+    return NSG_OK;
+}
+
+int roundUp(int a, int b) { return (a + b - 1) / b * b; }
+
+int enqueueForward(nsg_evaluator* ev, size_t n) {
+    const int B = (int)n;
+    const int prec = ev->prec;
+    hipStream_t s = ev->stream;
+    const nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount);
+
+    const bool prof = ev->profile;
+    if (prof && ev->evUsed + 4 > (int)ev->ev.size()) {
+        int rc = drainProfile(ev);
+        if (rc) return rc;
+    }
+    hipEvent_t* e = prof ? &ev->ev[ev->evUsed] : nullptr;
+    if (prof) NSG_HIP(hipEventRecord(e[0], s));
+
+    // feature planes (replaces cuda::extractBits, trt.cc:255-258)
+    NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, B,
+                                      ev->numChannels, ev->cpad, prec, s));
+    // stem
+    void* x = ev->act[0].p;
+    void* y = ev->act[1].p;
+    void* z = ev->act[2].p;
+    NSG_HIP(nsg::launchConv3x3(ev->planes.p, ev->stem.w.p, (const float*)ev->stem.bias.p,
+                               nullptr, x, B, ev->cpad, ev->F, 1, prec, plan, s));
+    if (prof) NSG_HIP(hipEventRecord(e[1], s));
+    for (int k = 0; k < ev->blocks; ++k) {
+        NSG_HIP(nsg::launchConv3x3(x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p,
+                                   nullptr, y, B, ev->F, ev->F, 1, prec, plan, s));
+        NSG_HIP(nsg::launchConv3x3(y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p,
+                                   x, z, B, ev->F, ev->F, 1, prec, plan, s));
+        void* t = x; x = z; z = t;
+    }
+    if (prof) NSG_HIP(hipEventRecord(e[2], s));
+    ev->trunkOut = x;
+    // heads
+    NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p,
+                             (float*)ev->policy.p, ev->vfeat.p, B, ev->F, ev->headsCout,
+                             ev->vc, ev->fc1K, prec, s));
+    NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->fc1.w.p, (const float*)ev->fc1.bias.p,
+                             (float*)ev->hidden.p, B, ev->fc1K, ev->vh, 1, prec, s));
+    NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->fc2W.p,
+                                (const float*)ev->fc2B.p, (float*)ev->value.p,
+                                (float*)ev->draw.p, B, ev->vh, s));
+    if (prof) {
+        NSG_HIP(hipEventRecord(e[3], s));
+        ev->evUsed += 4;
+        ev->pendingTrunkLaunchesPerFwd = 2 * ev->blocks;
+    }
+    return NSG_OK;
+}
+
+int checkCompute(nsg_evaluator* ev, size_t n) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    if (!ev->loaded) return fail(NSG_E_NOT_LOADED, "no weights loaded (call nsg_load first)");
+    if (n == 0 || n > (size_t)ev->batchMax)
+        return fail(NSG_E_INVALID, "batch size %zu outside [1, %d]", n, ev->batchMax);
+    return NSG_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* nsg_last_error(void) { return gLastError.c_str(); }
+const char* nsg_version(void) { return "nsg 0.1 (gfx950)"; }
+
+int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator** out) {
+    if (!out) return fail(NSG_E_INVALID, "null out pointer");
+    *out = nullptr;
+    if (batch_size_max <= 0 || batch_size_max > 65535 || num_channels <= 0 || num_channels > 1024)
+        return fail(NSG_E_INVALID, "bad batch_size_max/num_channels");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(NSG_E_HIP, "no HIP device available (%s): this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (gpu_id < 0 || gpu_id >= count) return fail(NSG_E_INVALID, "gpu_id %d out of range", gpu_id);
+    std::unique_ptr<nsg_evaluator> ev(new nsg_evaluator());
+    ev->gpu = gpu_id;
+    ev->batchMax = batch_size_max;
+    ev->numChannels = num_channels;
+    NSG_HIP(hipSetDevice(gpu_id));
+    NSG_HIP(hipGetDeviceProperties(&ev->prop, gpu_id));
+    int rc;
+    // trt.cc:57-77: device buffers sized for BatchSizeMax, zero-initialised
+    if ((rc = ev->input.alloc((size_t)batch_size_max * num_channels * NSG_BITBOARD_BYTES, true))) return rc;
+    if ((rc = ev->policy.alloc((size_t)batch_size_max * NSG_MOVE_INDEX_MAX * 4, true))) return rc;
+    if ((rc = ev->value.alloc((size_t)batch_size_max * 4, true))) return rc;
+    if ((rc = ev->draw.alloc((size_t)batch_size_max * 4, true))) return rc;
+    // trt.cc:79
+    NSG_HIP(hipStreamCreateWithFlags(&ev->stream, hipStreamNonBlocking));
+    *out = ev.release();
+    return NSG_OK;
+}
+
+int nsg_destroy(nsg_evaluator* ev) {
+    if (!ev) return NSG_OK;
+    (void)hipSetDevice(ev->gpu);
+    if (ev->stream) {
+        (void)hipStreamSynchronize(ev->stream);
+    }
+    for (hipEvent_t e : ev->ev) (void)hipEventDestroy(e);
+    if (ev->stream) (void)hipStreamDestroy(ev->stream);
+    delete ev;
+    return NSG_OK;
+}
+
+int nsg_set_precision(nsg_evaluator* ev, int precision) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    if (ev->loaded) return fail(NSG_E_INVALID, "precision must be chosen before nsg_load");
+    if (precision < NSG_PRECISION_FP32 || precision > NSG_PRECISION_BF16)
+        return fail(NSG_E_INVALID, "unknown precision %d", precision);
+    ev->prec = precision;
+    return NSG_OK;
+}
+
+int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
+    if (!ev || !blob) return fail(NSG_E_INVALID, "null argument");
+    int rc = bind(ev);
+    if (rc) return rc;
+    NetView nv;
+    if ((rc = parseBlob(blob, size, &nv))) return rc;
+    if (nv.cin != ev->numChannels)
+        return fail(NSG_E_FORMAT, "weight file expects %d input planes, evaluator has %d", nv.cin,
+                    ev->numChannels);
+    // trt.cc:193-210: the policy output must have ml::MoveIndexMax elements
+    if (nv.pc * NSG_NUM_SQUARES != NSG_MOVE_INDEX_MAX)
+        return fail(NSG_E_FORMAT, "Unexpected PolicySize: %d (expected: %d).",
+                    nv.pc * NSG_NUM_SQUARES, NSG_MOVE_INDEX_MAX);
+    if (nv.F % 64 != 0) return fail(NSG_E_FORMAT, "trunk width %d is not a multiple of 64", nv.F);
+    if (nv.vh % 64 != 0) return fail(NSG_E_FORMAT, "value hidden width %d is not a multiple of 64", nv.vh);
+
+    const int prec = ev->prec;
+    const int kc = nsg::chunkChannels(prec);
+    const int es = nsg::elemSize(prec);
+    ev->loaded = false;
+    ev->F = nv.F; ev->blocks = nv.blocks; ev->vc = nv.vc; ev->vh = nv.vh;
+    ev->cpad = roundUp(nv.cin, kc);
+    ev->headsCout = roundUp(nv.vc + nv.pc, 64);
+    ev->fc1K = roundUp(81 * nv.vc, kc);
+    ev->params = nv.params;
+
+    std::vector<double> scale;
+    std::vector<float> bias;
+    // stem
+    foldBn(nv.stemBn, nv.F, nv.eps, &scale, &bias);
+    {
+        Conv3Ctx c{nv.stemW, scale.data(), nv.cin};
+        if ((rc = uploadLayer(conv3Get, &c, 9, nv.cin, ev->cpad, nv.F, prec, bias, &ev->stem))) return rc;
+    }
+    ev->conv1.clear(); ev->conv2.clear();
+    ev->conv1.resize(nv.blocks); ev->conv2.resize(nv.blocks);
+    for (int k = 0; k < nv.blocks; ++k) {
+        foldBn(nv.bn1[k], nv.F, nv.eps, &scale, &bias);
+        Conv3Ctx c1{nv.w1[k], scale.data(), nv.F};
+        if ((rc = uploadLayer(conv3Get, &c1, 9, nv.F, nv.F, nv.F, prec, bias, &ev->conv1[k]))) return rc;
+        foldBn(nv.bn2[k], nv.F, nv.eps, &scale, &bias);
+        Conv3Ctx c2{nv.w2[k], scale.data(), nv.F};
+        if ((rc = uploadLayer(conv3Get, &c2, 9, nv.F, nv.F, nv.F, prec, bias, &ev->conv2[k]))) return rc;
+    }
+    // heads: [value conv (BN folded) | policy conv | zero pad]
+    {
+        foldBn(nv.valBn, nv.vc, nv.eps, &scale, &bias);
+        std::vector<float> hb(ev->headsCout, 0.f);
+        for (int i = 0; i < nv.vc; ++i) hb[i] = bias[i];
+        for (int i = 0; i < nv.pc; ++i) hb[nv.vc + i] = nv.polB[i];
+        HeadsCtx c{nv.valW, scale.data(), nv.polW, nv.F, nv.vc, nv.pc};
+        if ((rc = uploadLayer(headsGet, &c, 1, nv.F, nv.F, ev->headsCout, prec, hb, &ev->heads))) return rc;
+    }
+    {
+        std::vector<float> b1(nv.fc1B, nv.fc1B + nv.vh);
+        Fc1Ctx c{nv.fc1W, nv.vc};
+        if ((rc = uploadLayer(fc1Get, &c, 1, 81 * nv.vc, ev->fc1K, nv.vh, prec, b1, &ev->fc1))) return rc;
+    }
+    if ((rc = ev->fc2W.alloc((size_t)2 * nv.vh * 4, false))) return rc;
+    if ((rc = ev->fc2B.alloc(8, false))) return rc;
+    NSG_HIP(hipMemcpy(ev->fc2W.p, nv.fc2W, (size_t)2 * nv.vh * 4, hipMemcpyHostToDevice));
+    NSG_HIP(hipMemcpy(ev->fc2B.p, nv.fc2B, 8, hipMemcpyHostToDevice));
+
+    // activation buffers: whole workgroups of up to 2 boards
+    const size_t bpad = (size_t)roundUp(ev->batchMax, 2);
+    if ((rc = ev->planes.alloc(bpad * 81 * ev->cpad * es, true))) return rc;
+    for (int i = 0; i < 3; ++i)
+        if ((rc = ev->act[i].alloc(bpad * 81 * nv.F * es, true))) return rc;
+    if ((rc = ev->vfeat.alloc((size_t)ev->batchMax * ev->fc1K * es, true))) return rc;
+    if ((rc = ev->hidden.alloc((size_t)ev->batchMax * nv.vh * 4, true))) return rc;
+    NSG_HIP(hipDeviceSynchronize());
+    ev->loaded = true;
+    return NSG_OK;
+}
+
+int nsg_load(nsg_evaluator* ev, const char* path) {
+    if (!ev || !path) return fail(NSG_E_INVALID, "null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(NSG_E_IO, "Could not open the file: %s", path); // trt.cc:34-36
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz <= 0) {
+        fclose(f);
+        return fail(NSG_E_IO, "empty weight file: %s", path);
+    }
+    std::vector<unsigned char> blob((size_t)sz);
+    const size_t got = fread(blob.data(), 1, (size_t)sz, f);
+    fclose(f);
+    if (got != (size_t)sz) return fail(NSG_E_IO, "short read on %s", path);
+    return nsg_load_memory(ev, blob.data(), blob.size());
+}
+
+int nsg_load_device_blob(nsg_evaluator* ev, const void* device_blob, size_t size) {
+    if (!ev || !device_blob) return fail(NSG_E_INVALID, "null argument");
+    int rc = bind(ev);
+    if (rc) return rc;
+    std::vector<unsigned char> blob(size);
+    NSG_HIP(hipMemcpy(blob.data(), device_blob, size, hipMemcpyDeviceToHost));
+    return nsg_load_memory(ev, blob.data(), size);
+}
+
+int nsg_compute_nonblocking(nsg_evaluator* ev, const void* features, size_t batch_size,
+                            float* dst_policy, float* dst_win_rate, float* dst_draw_rate) {
+    int rc = checkCompute(ev, batch_size);
+    if (rc) return rc;
+    if (!features || !dst_policy || !dst_win_rate || !dst_draw_rate)
+        return fail(NSG_E_INVALID, "null buffer");
+    // trt.cc:237-238: exactly one batch in flight per executor
+    if (hipStreamQuery(ev->stream) == hipErrorNotReady)
+        return fail(NSG_E_BUSY, "computeNonBlocking called while a batch is in flight");
+    // trt.cc:240-242
+    NSG_HIP(hipMemcpyAsync(ev->input.p, features,
+                           batch_size * ev->numChannels * NSG_BITBOARD_BYTES,
+                           hipMemcpyHostToDevice, ev->stream));
+    if ((rc = enqueueForward(ev, batch_size))) return rc;
+    // trt.cc:265-271
+    NSG_HIP(hipMemcpyAsync(dst_policy, ev->policy.p, batch_size * NSG_MOVE_INDEX_MAX * sizeof(float),
+                           hipMemcpyDeviceToHost, ev->stream));
+    NSG_HIP(hipMemcpyAsync(dst_win_rate, ev->value.p, batch_size * sizeof(float),
+                           hipMemcpyDeviceToHost, ev->stream));
+    NSG_HIP(hipMemcpyAsync(dst_draw_rate, ev->draw.p, batch_size * sizeof(float),
+                           hipMemcpyDeviceToHost, ev->stream));
+    return NSG_OK;
+}
+
+int nsg_await(nsg_evaluator* ev) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    NSG_HIP(hipStreamSynchronize(ev->stream)); // trt.cc:281-283
+    return NSG_OK;
+}
+
+int nsg_compute_blocking(nsg_evaluator* ev, const void* features, size_t batch_size,
+                         float* dst_policy, float* dst_win_rate, float* dst_draw_rate) {
+    int rc = nsg_compute_nonblocking(ev, features, batch_size, dst_policy, dst_win_rate,
+                                     dst_draw_rate); // trt.cc:274-279
+    if (rc) return rc;
+    return nsg_await(ev);
+}
+
+int nsg_is_computing(nsg_evaluator* ev) {
+    if (!ev) return 0;
+    return hipStreamQuery(ev->stream) == hipErrorNotReady ? 1 : 0; // trt.cc:285-287
+}
+
+int nsg_reset_gpu(nsg_evaluator* ev) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    return bind(ev); // trt.cc:289-291
+}
+
+int nsg_extract_bits(float* dst, const uint64_t* src, int batch_size, int num_channels,
+                     int channels_first, void* hip_stream) {
+    if (!dst || !src || batch_size <= 0 || num_channels <= 0)
+        return fail(NSG_E_INVALID, "bad extract_bits argument"); // extractbit.cu:78 assert
+    if (!channels_first && num_channels > 1024)
+        return fail(NSG_E_INVALID, "NumChannels > 1024"); // extractbit.cu:91
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (channels_first) {
+        NSG_HIP(nsg::launchExtractBitsNCHW(dst, src, batch_size, num_channels, s));
+    } else {
+        NSG_HIP(nsg::launchExtractBitsNHWC(dst, src, batch_size, num_channels, s));
+    }
+    return NSG_OK;
+}
+
+int nsg_host_register(void* ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail(NSG_E_INVALID, "bad host_register argument");
+    NSG_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return NSG_OK;
+}
+
+int nsg_host_unregister(void* ptr) {
+    if (!ptr) return fail(NSG_E_INVALID, "null pointer");
+    NSG_HIP(hipHostUnregister(ptr));
+    return NSG_OK;
+}
+
+int nsg_upload_features(nsg_evaluator* ev, const void* features, size_t batch_size) {
+    if (!ev || !features || batch_size == 0 || batch_size > (size_t)ev->batchMax)
+        return fail(NSG_E_INVALID, "bad upload_features argument");
+    int rc = bind(ev);
+    if (rc) return rc;
+    NSG_HIP(hipMemcpyAsync(ev->input.p, features, batch_size * ev->numChannels * NSG_BITBOARD_BYTES,
+                           hipMemcpyHostToDevice, ev->stream));
+    NSG_HIP(hipStreamSynchronize(ev->stream));
+    return NSG_OK;
+}
+
+int nsg_forward_resident(nsg_evaluator* ev, size_t batch_size) {
+    int rc = checkCompute(ev, batch_size);
+    if (rc) return rc;
+    return enqueueForward(ev, batch_size);
+}
+
+int nsg_download_outputs(nsg_evaluator* ev, size_t batch_size, float* dst_policy,
+                         float* dst_win_rate, float* dst_draw_rate) {
+    int rc = checkCompute(ev, batch_size);
+    if (rc) return rc;
+    NSG_HIP(hipMemcpyAsync(dst_policy, ev->policy.p, batch_size * NSG_MOVE_INDEX_MAX * sizeof(float),
+                           hipMemcpyDeviceToHost, ev->stream));
+    NSG_HIP(hipMemcpyAsync(dst_win_rate, ev->value.p, batch_size * sizeof(float),
+                           hipMemcpyDeviceToHost, ev->stream));
+    NSG_HIP(hipMemcpyAsync(dst_draw_rate, ev->draw.p, batch_size * sizeof(float),
+                           hipMemcpyDeviceToHost, ev->stream));
+    NSG_HIP(hipStreamSynchronize(ev->stream));
+    return NSG_OK;
+}
+
+int nsg_download_trunk(nsg_evaluator* ev, size_t batch_size, float* dst) {
+    int rc = checkCompute(ev, batch_size);
+    if (rc) return rc;
+    if (!ev->trunkOut) return fail(NSG_E_INVALID, "no forward has run yet");
+    const size_t bytes = batch_size * ev->F * 81 * sizeof(float);
+    if (ev->scratch.bytes < bytes && (rc = ev->scratch.alloc(bytes, false))) return rc;
+    NSG_HIP(nsg::launchActToNCHW(ev->trunkOut, (float*)ev->scratch.p, (int)batch_size, ev->F,
+                                 ev->prec, ev->stream));
+    NSG_HIP(hipMemcpyAsync(dst, ev->scratch.p, bytes, hipMemcpyDeviceToHost, ev->stream));
+    NSG_HIP(hipStreamSynchronize(ev->stream));
+    return NSG_OK;
+}
+
+int nsg_profile_enable(nsg_evaluator* ev, int enable) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    int rc = bind(ev);
+    if (rc) return rc;
+    if (enable && ev->ev.empty()) {
+        ev->ev.resize(kMaxEventPairs * 4);
+        for (auto& e : ev->ev) NSG_HIP(hipEventCreate(&e));
+    }
+    if (!enable && (rc = drainProfile(ev))) return rc;
+    ev->profile = enable != 0;
+    return NSG_OK;
+}
+
+int nsg_profile_read(nsg_evaluator* ev, double* trunk_ms_total, uint64_t* trunk_launches,
+                     double* forward_ms_total, uint64_t* forwards) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    int rc = drainProfile(ev);
+    if (rc) return rc;
+    if (trunk_ms_total) *trunk_ms_total = ev->trunkMs;
+    if (trunk_launches) *trunk_launches = ev->trunkLaunches;
+    if (forward_ms_total) *forward_ms_total = ev->fwdMs;
+    if (forwards) *forwards = ev->forwards;
+    ev->trunkMs = ev->fwdMs = 0;
+    ev->trunkLaunches = ev->forwards = 0;
+    return NSG_OK;
+}
+
+int nsg_get_info(nsg_evaluator* ev, nsg_info* info) {
+    if (!ev || !info) return fail(NSG_E_INVALID, "null argument");
+    memset(info, 0, sizeof(*info));
+    info->gpu_id = ev->gpu;
+    info->batch_size_max = ev->batchMax;
+    info->num_channels = ev->numChannels;
+    info->channels = ev->F;
+    info->blocks = ev->blocks;
+    info->value_channels = ev->vc;
+    info->value_hidden = ev->vh;
+    info->precision = ev->prec;
+    info->loaded = ev->loaded ? 1 : 0;
+    info->compute_units = ev->prop.multiProcessorCount;
+    info->clock_khz = ev->prop.clockRate;
+    info->param_count = ev->params;
+    const double F = ev->F, N = ev->blocks, C = ev->numChannels;
+    // stem + trunk + 1x1 policy (value/draw heads excluded)
+    info->flops_per_position = 2.0 * 81 * 9 * C * F + N * 2 * (2.0 * 81 * 9 * F * F) + 2.0 * 81 * 27 * F;
+    info->trunk_conv_flops_per_position = 2.0 * 81 * 9 * F * F;
+    snprintf(info->device_name, sizeof(info->device_name), "%s", ev->prop.name);
+    return NSG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// CPU stand-in executors (src/infer/zero.cc, nothing.cc, random.cc).
+// ---------------------------------------------------------------------------
+struct nsg_cpu_executor {
+    int kind;
+    std::mt19937_64 rng; // random.h:41
+};
+
+int nsg_cpu_executor_create(int kind, uint64_t seed, nsg_cpu_executor** out) {
+    if (!out || kind < 0 || kind > 2) return fail(NSG_E_INVALID, "bad cpu executor kind");
+    *out = new nsg_cpu_executor{kind, std::mt19937_64(seed)}; // random.cc:21-23
+    return NSG_OK;
+}
+
+int nsg_cpu_executor_destroy(nsg_cpu_executor* ex) {
+    delete ex;
+    return NSG_OK;
+}
+
+int nsg_cpu_executor_compute(nsg_cpu_executor* ex, const void*, size_t batch_size,
+                             float* dst_policy, float* dst_win_rate, float* dst_draw_rate) {
+    if (!ex) return fail(NSG_E_INVALID, "null executor");
+    if (ex->kind == 0) { // zero.cc:25-31
+        memset(dst_policy, 0, batch_size * NSG_MOVE_INDEX_MAX * sizeof(float));
+        memset(dst_win_rate, 0, batch_size * sizeof(float));
+        memset(dst_draw_rate, 0, batch_size * sizeof(float));
+    } else if (ex->kind == 2) { // random.cc:28-42
+        // one distribution object shared by every executor, as the
+        // function-static of random.cc:32 is
+        static std::uniform_real_distribution<float> distribution(0, 1);
+        for (size_t i = 0; i < batch_size; ++i) {
+            for (size_t j = 0; j < NSG_MOVE_INDEX_MAX; ++j)
+                dst_policy[i * NSG_MOVE_INDEX_MAX + j] = distribution(ex->rng);
+            dst_win_rate[i] = distribution(ex->rng);
+            dst_draw_rate[i] = distribution(ex->rng);
+        }
+    } // kind 1 = Nothing: nothing.cc:22-24
+    return NSG_OK;
+}
+
+} // extern "C"
