@@ -93,17 +93,11 @@ def main():
 
     # weights: rank 0 builds the synthetic blob; one RCCL broadcast over xGMI
     # replaces every executor re-reading the model file (trt.cc:109-186).
+    blob = None
     if rank == 0:
         blob = nsg.weights.to_blob(nsg.weights.make_random(blocks, channels, seed=0, bn="identity"))
-        size = torch.tensor([len(blob)], dtype=torch.int64, device="cuda")
-    else:
-        blob, size = None, torch.zeros(1, dtype=torch.int64, device="cuda")
     if distributed:
-        dist.broadcast(size, src=0)
-        dev_blob = torch.empty(int(size.item()), dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            dev_blob.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-        dist.broadcast(dev_blob, src=0)
+        dev_blob = nsg.dist.broadcast_blob(blob, src=0, device="cuda")
         torch.cuda.synchronize()
         ev.load_device_blob(dev_blob.data_ptr(), dev_blob.numel())
         del dev_blob
@@ -112,7 +106,7 @@ def main():
     info = ev.info()
 
     # synthetic positions: B distinct per rank (distinct across ranks too)
-    bb = nsg.synth.random_batch(B, 86, seed=nsg.synth.SEED + rank, distinct=True)
+    bb = nsg.synth.random_batch(B, 86, seed=nsg.dist.shard_seed(nsg.synth.SEED, rank), distinct=True)
     ev.upload_features(bb)
 
     def barrier():
@@ -135,9 +129,7 @@ def main():
     ev.profile_enable(False)
 
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = nsg.dist.max_over_ranks(dt, device="cuda")
 
     out = None
     if rank == 0:

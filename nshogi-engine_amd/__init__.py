@@ -23,10 +23,10 @@ from .capi import (  # noqa: F401
     MOVE_INDEX_MAX,
     NUM_SQUARES,
 )
-from . import weights, synth  # noqa: F401
+from . import weights, synth, dist  # noqa: F401
 
 __all__ = [
     "NsgError", "Evaluator", "CpuExecutor", "extract_bits", "load_library",
-    "library_path", "weights", "synth", "PRECISION_FP32", "PRECISION_FP16",
+    "library_path", "weights", "synth", "dist", "PRECISION_FP32", "PRECISION_FP16",
     "PRECISION_BF16", "MOVE_INDEX_MAX", "NUM_SQUARES",
 ]
