@@ -217,16 +217,21 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void tileKernel(const Args A) {
             st[k];                                                                       \
     }
 
-    // weight stream: slab q = (kc*taps + tap)*2 + s, NFRAG records per wave
+    // weight stream: slab q = (kc*taps + tap)*2 + s, NFRAG 1-KiB records per wave,
+    // held in a register ring kRing slabs deep (slab q+2 is requested while slab q
+    // computes, so a weight load has a whole slab of MFMAs to cover its L2 latency).
+    constexpr int kSlabs = 2 * G::kTaps;               // slabs per channel chunk
+    constexpr int kRing = (kSlabs % 3 == 0) ? 3 : 2;
+    constexpr int kMfmaPerPair = (PREC == kFp32) ? 4 : 1;
     const size_t slabStride = (size_t)nft * 64;
     const u32x4* wp = A.w + (size_t)waveGroup * NFRAG * 64 + lane;
-    u32x4 w0[NFRAG], w1[NFRAG];
+    u32x4 w[kRing][NFRAG];
 #pragma unroll
     for (int j = 0; j < NFRAG; ++j) {
-        w0[j] = wp[j * 64];
-        w1[j] = wp[slabStride + j * 64];
+        w[0][j] = wp[j * 64];
+        w[1][j] = wp[slabStride + j * 64];
     }
-    wp += 2 * slabStride;
+    wp += 2 * slabStride; // -> slab 2
 
     f32x4 acc[G::kMF][NFRAG];
 #pragma unroll
@@ -239,39 +244,51 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void tileKernel(const Args A) {
     NSG_STAGE_WRITE(0)
     __syncthreads();
 
-    constexpr int kTapUnroll = (PREC == kFp32) ? 1 : G::kTaps;
+    u32x4 a[2][G::kMF]; // row fragments: current slab / next slab
     for (int kc = 0; kc < nkc; ++kc) {
+        const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
+#pragma unroll
+        for (int f = 0; f < G::kMF; ++f) // slab 0 of this chunk (just published by the barrier)
+            a[0][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + (G::kBoards ? 0 : 0) +
+                                                       (G::kBoards ? ((0 / 3 - 1) * 10 + (0 % 3 - 1) + 11) * 16 : 0));
+        // next chunk's tile: global -> registers now, registers -> LDS after the last slab
         // (the last iteration re-loads its own chunk: harmless, keeps st[] in registers)
         NSG_STAGE_LOAD(kc + 1 < nkc ? kc + 1 : kc)
-        const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
-#pragma unroll kTapUnroll
-        for (int t = 0; t < G::kTaps; ++t) {
-            const int tapOff = G::kBoards ? ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16 : 0;
-            {
-                u32x4 a[G::kMF];
+#pragma unroll
+        for (int s = 0; s < kSlabs; ++s) {
+            // -- requests for later slabs
+            if (s + 1 < kSlabs) {
+                const int t1 = (s + 1) >> 1;
+                const int off1 = (G::kBoards ? ((t1 / 3 - 1) * 10 + (t1 % 3 - 1) + 11) * 16 : 0) +
+                                 ((s + 1) & 1) * 4 * G::kPlane;
 #pragma unroll
                 for (int f = 0; f < G::kMF; ++f)
-                    a[f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + tapOff);
-#pragma unroll
-                for (int j = 0; j < NFRAG; ++j)
-#pragma unroll
-                    for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w0[j], a[f]);
-#pragma unroll
-                for (int j = 0; j < NFRAG; ++j) w0[j] = wp[j * 64];
+                    a[(s + 1) & 1][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + off1);
             }
-            {
-                u32x4 a[G::kMF];
+            if constexpr (kRing == 3) {
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f)
-                    a[f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + tapOff + 4 * G::kPlane);
-#pragma unroll
-                for (int j = 0; j < NFRAG; ++j)
-#pragma unroll
-                    for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w1[j], a[f]);
-#pragma unroll
-                for (int j = 0; j < NFRAG; ++j) w1[j] = wp[slabStride + j * 64];
+                for (int j = 0; j < NFRAG; ++j) w[(s + 2) % 3][j] = wp[j * 64];
             }
-            wp += 2 * slabStride;
+            // -- this slab's MFMAs
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+                for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w[s % kRing][j], a[s & 1][f]);
+            if constexpr (kRing == 2) {
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) w[s % 2][j] = wp[j * 64];
+            }
+            wp += slabStride;
+            if constexpr (kRing == 3) {
+                // interleave: one LDS read (+ one weight load) per NFRAG row-fragment MFMAs
+#pragma unroll
+                for (int f = 0; f < G::kMF; ++f) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
+                    if (f < NFRAG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x008, NFRAG * kMfmaPerPair, 0); // MFMA
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0); // nothing sinks out of its slab
         }
         NSG_STAGE_WRITE((kc + 1) & 1)
         __syncthreads();
