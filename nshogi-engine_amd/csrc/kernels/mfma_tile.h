@@ -148,8 +148,13 @@ struct Args {
     int vfeatStride;          // kHeads: elements per board row of vfeat (>= 81*VC)
 };
 
+// Single-board conv tiles are small enough for two workgroups per CU (two waves
+// per SIMD): the second argument caps registers at 256 so both fit.
+template <int MODE, int SIZE, int NWAVES>
+constexpr int minWavesPerSimd() { return (MODE == kConv && SIZE == 1 && NWAVES >= 3) ? 2 : 1; }
+
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES>
-__global__ __launch_bounds__(NWAVES * 64, 1) void tileKernel(const Args A) {
+__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>())) void tileKernel(const Args A) {
     using G = Geom<MODE, SIZE, NWAVES>;
     constexpr int ES = (PREC == kFp32) ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

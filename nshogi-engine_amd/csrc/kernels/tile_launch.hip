@@ -2,6 +2,7 @@
 // precision dispatch, weight packing, and the small value-output kernel.
 #include "mfma_tile.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace nsg {
@@ -18,6 +19,10 @@ ConvPlan chooseConvPlan(int batch, int cout, int computeUnits) {
     // grid still covers most of the chip.
     const int wgs2 = ((batch + 1) / 2) * (groups / p.nwaves);
     p.nb = (wgs2 * 4 >= computeUnits * 3) ? 2 : 1;
+    if (const char* e = getenv("NSG_CONV_NB")) { // tuning knob
+        const int v = atoi(e);
+        if (v == 1 || v == 2) p.nb = v;
+    }
     return p;
 }
 
