@@ -30,8 +30,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2516.6, "bf16": 2516.6}
-DTYPE_NAME = {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}
+PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2516.6, "bf16": 2516.6, "f16x3": 2516.6}
+DTYPE_NAME = {"fp32": "f32", "fp16": "f16", "bf16": "bf16", "f16x3": "f16x3 (split f16 hi/lo, f32 accumulate)"}
 
 
 def cpu_baseline(seconds=12.0):
@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--net", default="20x256", help="blocks x channels, e.g. 10x192, 20x256, 40x384")
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--precision", default=os.environ.get("NSG_BENCH_PRECISION", "fp32"),
-                    choices=["fp32", "fp16", "bf16"])
+                    choices=["fp32", "fp16", "bf16", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     args = ap.parse_args()

@@ -47,6 +47,10 @@ extern "C" {
 #define NSG_PRECISION_FP32 0
 #define NSG_PRECISION_FP16 1
 #define NSG_PRECISION_BF16 2
+/* f32-equivalent on the f16 matrix cores: values carried as (f16 hi, f16 lo)
+ * pairs, products evaluated as hi*hi + lo*hi + hi*lo with f32 accumulation
+ * (~22 significant bits). */
+#define NSG_PRECISION_F16X3 3
 
 typedef struct nsg_evaluator nsg_evaluator;
 

@@ -20,6 +20,7 @@ from .capi import (  # noqa: F401
     PRECISION_FP32,
     PRECISION_FP16,
     PRECISION_BF16,
+    PRECISION_F16X3,
     MOVE_INDEX_MAX,
     NUM_SQUARES,
 )
@@ -28,5 +29,5 @@ from . import weights, synth, dist  # noqa: F401
 __all__ = [
     "NsgError", "Evaluator", "CpuExecutor", "extract_bits", "load_library",
     "library_path", "weights", "synth", "dist", "PRECISION_FP32", "PRECISION_FP16",
-    "PRECISION_BF16", "MOVE_INDEX_MAX", "NUM_SQUARES",
+    "PRECISION_BF16", "PRECISION_F16X3", "MOVE_INDEX_MAX", "NUM_SQUARES",
 ]

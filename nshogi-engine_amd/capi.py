@@ -13,11 +13,12 @@ import numpy as np
 PRECISION_FP32 = 0
 PRECISION_FP16 = 1
 PRECISION_BF16 = 2
+PRECISION_F16X3 = 3
 MOVE_INDEX_MAX = 2187
 NUM_SQUARES = 81
 BITBOARD_BYTES = 16
 
-_PREC_NAMES = {"fp32": 0, "f32": 0, "fp16": 1, "f16": 1, "bf16": 2}
+_PREC_NAMES = {"fp32": 0, "f32": 0, "fp16": 1, "f16": 1, "bf16": 2, "f16x3": 3}
 
 
 class NsgError(RuntimeError):

@@ -126,8 +126,25 @@ __global__ __launch_bounds__(kThreads) void extractAct(
                 v[i] = 0u;
             }
         }
+        const uint32_t* vv = v;
+        (void)vv;
         const size_t e = ((size_t)b * 81 + sq) * cpad + c0;
-        if constexpr (PREC == kFp32) {
+        if constexpr (PREC == kF16x3) {
+            // row = 128-byte chunks of 32 channels: [32 x f16 hi][32 x f16 lo]
+            unsigned char* row = (unsigned char*)dstv + ((size_t)b * 81 + sq) * cpad * 4 +
+                                 (size_t)(c0 >> 5) * 128 + (c0 & 31) * 2;
+            uint16_t hb[4], lb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = fminf(fmaxf(__uint_as_float(vv[i]), -65000.f), 65000.f);
+                const _Float16 h = (_Float16)v;
+                const _Float16 l = (_Float16)(v - (float)h);
+                hb[i] = __builtin_bit_cast(uint16_t, h);
+                lb[i] = __builtin_bit_cast(uint16_t, l);
+            }
+            *reinterpret_cast<uint2*>(row) = make_uint2(hb[0] | ((uint32_t)hb[1] << 16), hb[2] | ((uint32_t)hb[3] << 16));
+            *reinterpret_cast<uint2*>(row + 64) = make_uint2(lb[0] | ((uint32_t)lb[1] << 16), lb[2] | ((uint32_t)lb[3] << 16));
+        } else if constexpr (PREC == kFp32) {
             *reinterpret_cast<uint4*>((uint32_t*)dstv + e) =
                 make_uint4(v[0], v[1], v[2], v[3]);
         } else if constexpr (PREC == kFp16) {
@@ -153,7 +170,11 @@ __global__ void actToNCHW(const void* __restrict__ xv, float* __restrict__ dst, 
         const int sq = j - ch * 81;
         const size_t e = ((size_t)b * 81 + sq) * c + ch;
         float v;
-        if constexpr (PREC == kFp32) {
+        if constexpr (PREC == kF16x3) {
+            const unsigned char* row = (const unsigned char*)xv + ((size_t)b * 81 + sq) * c * 4 +
+                                       (size_t)(ch >> 5) * 128 + (ch & 31) * 2;
+            v = (float)*(const _Float16*)row + (float)*(const _Float16*)(row + 64);
+        } else if constexpr (PREC == kFp32) {
             v = ((const float*)xv)[e];
         } else if constexpr (PREC == kFp16) {
             v = (float)((const _Float16*)xv)[e];
@@ -197,6 +218,9 @@ hipError_t launchExtractBitsAct(void* dst, const uint64_t* src, int batch,
     } else if (prec == kFp16) {
         hipLaunchKernelGGL(extractAct<kFp16>, dim3(batch), dim3(kThreads), smem,
                            stream, dst, (const uint4*)src, channels, cpad);
+    } else if (prec == kF16x3) {
+        hipLaunchKernelGGL(extractAct<kF16x3>, dim3(batch), dim3(kThreads), smem,
+                           stream, dst, (const uint4*)src, channels, cpad);
     } else {
         hipLaunchKernelGGL(extractAct<kBf16>, dim3(batch), dim3(kThreads), smem,
                            stream, dst, (const uint4*)src, channels, cpad);
@@ -210,6 +234,8 @@ hipError_t launchActToNCHW(const void* x, float* dst, int batch, int c,
         hipLaunchKernelGGL(actToNCHW<kFp32>, dim3(batch), dim3(256), 0, stream, x, dst, c);
     } else if (prec == kFp16) {
         hipLaunchKernelGGL(actToNCHW<kFp16>, dim3(batch), dim3(256), 0, stream, x, dst, c);
+    } else if (prec == kF16x3) {
+        hipLaunchKernelGGL(actToNCHW<kF16x3>, dim3(batch), dim3(256), 0, stream, x, dst, c);
     } else {
         hipLaunchKernelGGL(actToNCHW<kBf16>, dim3(batch), dim3(256), 0, stream, x, dst, c);
     }

@@ -14,11 +14,19 @@
 
 namespace nsg {
 
-enum Precision { kFp32 = 0, kFp16 = 1, kBf16 = 2 };
+// kF16x3: every value is carried as an (f16 hi, f16 lo) pair, hi = f16(v),
+// lo = f16(v - hi), and every product is evaluated as hi*hi + lo*hi + hi*lo on the
+// f16 MFMA with f32 accumulation: ~22 significant bits (f32 has 24) at three
+// 16-bit MFMAs per MAC instead of sixteen f32-MFMA cycles' worth.
+enum Precision { kFp32 = 0, kFp16 = 1, kBf16 = 2, kF16x3 = 3 };
 
-inline int elemSize(int prec) { return prec == kFp32 ? 4 : 2; }
+// Bytes one activation channel occupies (a kF16x3 pair is 2 + 2 bytes).
+inline int elemSize(int prec) { return (prec == kFp32 || prec == kF16x3) ? 4 : 2; }
 // Channels per 128-byte K chunk of the trunk convolution.
 inline int chunkChannels(int prec) { return 128 / elemSize(prec); }
+// MFMA K-slabs per (chunk, tap): two halves of the chunk, or for kF16x3 the three
+// products (w_hi,x_hi) (w_lo,x_hi) (w_hi,x_lo) over the chunk's 32 channels.
+inline int slabsPerTap(int prec) { return prec == kF16x3 ? 3 : 2; }
 
 // ---- feature-plane expansion (reference K1/K2, src/cuda/extractbit.cu) ----
 hipError_t launchExtractBitsNCHW(float* dst, const uint64_t* src, int batch,
@@ -48,8 +56,8 @@ ConvPlan chooseConvPlan(int batch, int cout, int computeUnits);
 inline int paddedBoards(int batch, int nb) { return (batch + nb - 1) / nb * nb; }
 hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
                          const void* residual, void* y, int batch, int cin,
-                         int cout, int relu, int prec, const ConvPlan& plan,
-                         hipStream_t stream);
+                         int cout, int relu, float accScale, int prec,
+                         const ConvPlan& plan, hipStream_t stream);
 
 // Policy 1x1 conv (27 ch, +bias, raw logits -> policy[b][c*81+sq] f32) and
 // value-feature 1x1 conv (VC ch, folded-BN bias, ReLU -> vfeat[b*vfeatStride + sq*VC+c] T)
@@ -58,12 +66,12 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
 hipError_t launchHeads(const void* x, const void* wfrag, const float* bias,
                        float* policy, void* vfeat, int batch, int channels,
                        int coutPadded, int valueChannels, int vfeatStride,
-                       int prec, hipStream_t stream);
+                       float accScale, int prec, hipStream_t stream);
 
 // y[rows][cout] f32 = (ReLU)(x[rows][kdim] T * W + bias): value MLP layer 1.
 hipError_t launchDense(const void* x, const void* wfrag, const float* bias,
                        float* y, int rows, int kdim, int cout, int relu,
-                       int prec, hipStream_t stream);
+                       float accScale, int prec, hipStream_t stream);
 
 // Value MLP layer 2 + squashing: o = w2 h + b2; value = (tanh(o0)+1)/2,
 // draw = sigmoid(o1).  One wave per board, lane-shuffle reduction.
@@ -79,8 +87,11 @@ size_t tileWeightRecords(int taps, int kdim, int cout, int prec);
 // channels [kReal, kdim) are zero padding, as are output channels for which
 // get() returns 0.
 typedef float (*WeightGetter)(const void* ctx, int n, int k, int tap);
+// `scale` multiplies every weight before conversion (a power of two chosen per
+// tensor for kF16x3 so hi and lo stay in f16's normal range; the kernel undoes it
+// exactly through accScale = 1/scale).
 void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
-                     int kdim, int cout, int prec, void* dst);
+                     int kdim, int cout, int prec, float scale, void* dst);
 
 // Debug: activations [batch][81][c] T -> f32 [batch][c][81].
 hipError_t launchActToNCHW(const void* x, float* dst, int batch, int c,

@@ -96,7 +96,7 @@ __device__ __forceinline__ void mfmaSlab(f32x4& acc, const u32x4& w, const u32x4
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
-    } else if constexpr (PREC == kFp16) {
+    } else if constexpr (PREC == kFp16 || PREC == kF16x3) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
     } else {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
@@ -105,7 +105,7 @@ __device__ __forceinline__ void mfmaSlab(f32x4& acc, const u32x4& w, const u32x4
 
 template <int PREC>
 __device__ __forceinline__ uint16_t toBits16(float v) {
-    if constexpr (PREC == kFp16) {
+    if constexpr (PREC == kFp16 || PREC == kF16x3) {
         return __builtin_bit_cast(uint16_t, (_Float16)v);
     } else {
         return __builtin_bit_cast(uint16_t, (__bf16)v);
@@ -123,6 +123,18 @@ __device__ __forceinline__ float unpackLo(uint32_t v) {
         return __uint_as_float(v << 16);
     }
 }
+// kF16x3: v -> (hi, lo) with hi = f16(v) (clamped to the finite f16 range), lo = f16(v - hi)
+__device__ __forceinline__ void splitF16(float v, uint16_t& hi, uint16_t& lo) {
+    v = fminf(fmaxf(v, -65000.f), 65000.f);
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, l);
+}
+__device__ __forceinline__ float f16BitsToF32(uint16_t b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+}
+
 template <int PREC>
 __device__ __forceinline__ float unpackHi(uint32_t v) {
     if constexpr (PREC == kFp16) {
@@ -146,6 +158,7 @@ struct Args {
     int relu;
     int valueChannels;        // kHeads: channels [0,VC) = value conv, [VC,VC+27) = policy
     int vfeatStride;          // kHeads: elements per board row of vfeat (>= 81*VC)
+    float accScale;           // accumulators are multiplied by this before the bias (kF16x3: 1/weight scale)
 };
 
 // Single-board conv tiles are small enough for two workgroups per CU (two waves
@@ -156,7 +169,9 @@ constexpr int minWavesPerSimd() { return (MODE == kConv && SIZE == 1 && NWAVES >
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES>
 __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>())) void tileKernel(const Args A) {
     using G = Geom<MODE, SIZE, NWAVES>;
-    constexpr int ES = (PREC == kFp32) ? 4 : 2;
+    constexpr int ES = (PREC == kFp32 || PREC == kF16x3) ? 4 : 2;
+    constexpr bool kSplit = (PREC == kF16x3);
+    static_assert(!kSplit || NFRAG == 4, "kF16x3 epilogue assumes 16 channels per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -225,7 +240,17 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
     // weight stream: slab q = (kc*taps + tap)*2 + s, NFRAG 1-KiB records per wave,
     // held in a register ring kRing slabs deep (slab q+2 is requested while slab q
     // computes, so a weight load has a whole slab of MFMAs to cover its L2 latency).
-    constexpr int kSlabs = 2 * G::kTaps;               // slabs per channel chunk
+    constexpr int kSlabsPerTap = kSplit ? 3 : 2;
+    constexpr int kSlabs = kSlabsPerTap * G::kTaps;    // slabs per channel chunk
+    // LDS byte offset of slab s's row fragments inside the chunk image: tap shift +
+    // which 4 of the 8 16-byte pieces (kF16x3: pieces 0-3 = hi, 4-7 = lo; slabs
+    // (w_hi,x_hi) (w_lo,x_hi) (w_hi,x_lo) -> hi, hi, lo)
+    auto slabOff = [](int s) constexpr {
+        const int t = s / kSlabsPerTap;
+        const int r = s % kSlabsPerTap;
+        const int piece = kSplit ? (r == 2 ? 4 : 0) : r * 4;
+        return (G::kBoards ? ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16 : 0) + piece * G::kPlane;
+    };
     constexpr int kRing = (kSlabs % 3 == 0) ? 3 : 2;
     constexpr int kMfmaPerPair = (PREC == kFp32) ? 4 : 1;
     const size_t slabStride = (size_t)nft * 64;
@@ -254,8 +279,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
         const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
 #pragma unroll
         for (int f = 0; f < G::kMF; ++f) // slab 0 of this chunk (just published by the barrier)
-            a[0][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + (G::kBoards ? 0 : 0) +
-                                                       (G::kBoards ? ((0 / 3 - 1) * 10 + (0 % 3 - 1) + 11) * 16 : 0));
+            a[0][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + slabOff(0));
         // next chunk's tile: global -> registers now, registers -> LDS after the last slab
         // (the last iteration re-loads its own chunk: harmless, keeps st[] in registers)
         NSG_STAGE_LOAD(kc + 1 < nkc ? kc + 1 : kc)
@@ -263,9 +287,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
         for (int s = 0; s < kSlabs; ++s) {
             // -- requests for later slabs
             if (s + 1 < kSlabs) {
-                const int t1 = (s + 1) >> 1;
-                const int off1 = (G::kBoards ? ((t1 / 3 - 1) * 10 + (t1 % 3 - 1) + 11) * 16 : 0) +
-                                 ((s + 1) & 1) * 4 * G::kPlane;
+                const int off1 = slabOff(s + 1);
 #pragma unroll
                 for (int f = 0; f < G::kMF; ++f)
                     a[(s + 1) & 1][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + off1);
@@ -319,9 +341,43 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
 #pragma unroll
         for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[f][j][r] + bv[j * 4 + r];
+            for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaf(acc[f][j][r], A.accScale, bv[j * 4 + r]);
 
-        if constexpr (MODE == kConv) {
+        if constexpr (MODE == kConv && kSplit) {
+            // row layout: 128-byte chunks of 32 channels = [32 x f16 hi][32 x f16 lo];
+            // this lane's 16 channels are 32 contiguous hi bytes and 32 contiguous lo bytes
+            const size_t e = grow * (size_t)A.cout * 4 + (size_t)(cbase >> 5) * 128 + (cbase & 31) * 2;
+            if constexpr (HAS_RES) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 rh = *reinterpret_cast<const u32x4*>(A.res + e + h * 16);
+                    const u32x4 rl = *reinterpret_cast<const u32x4*>(A.res + e + 64 + h * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[h * 8 + 2 * i] += f16BitsToF32((uint16_t)(rh[i] & 0xffffu)) + f16BitsToF32((uint16_t)(rl[i] & 0xffffu));
+                        v[h * 8 + 2 * i + 1] += f16BitsToF32((uint16_t)(rh[i] >> 16)) + f16BitsToF32((uint16_t)(rl[i] >> 16));
+                    }
+                }
+            }
+            if (A.relu) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            uint16_t hb[16], lb[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) splitF16(v[i], hb[i], lb[i]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 oh, ol;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    oh[i] = (uint32_t)hb[h * 8 + 2 * i] | ((uint32_t)hb[h * 8 + 2 * i + 1] << 16);
+                    ol[i] = (uint32_t)lb[h * 8 + 2 * i] | ((uint32_t)lb[h * 8 + 2 * i + 1] << 16);
+                }
+                *reinterpret_cast<u32x4*>(A.y + e + h * 16) = oh;
+                *reinterpret_cast<u32x4*>(A.y + e + 64 + h * 16) = ol;
+            }
+        } else         if constexpr (MODE == kConv) {
             const size_t e = (grow * (size_t)A.cout + cbase) * ES;
             if constexpr (HAS_RES) {
                 if constexpr (PREC == kFp32) {
@@ -371,7 +427,15 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
                 if (n < vc) {
                     const float r = fmaxf(v[i], 0.f);
                     const size_t e = (size_t)b * A.vfeatStride + (size_t)sq * vc + n;
-                    if constexpr (PREC == kFp32) {
+                    if constexpr (kSplit) {
+                        // dense-layer input row: K index kk = sq*vc + n, same chunked hi/lo layout
+                        const int kk = sq * vc + n;
+                        uint16_t hb, lb;
+                        splitF16(r, hb, lb);
+                        unsigned char* row = A.vfeat + (size_t)b * A.vfeatStride * 4 + (size_t)(kk >> 5) * 128 + (kk & 31) * 2;
+                        *reinterpret_cast<uint16_t*>(row) = hb;
+                        *reinterpret_cast<uint16_t*>(row + 64) = lb;
+                    } else if constexpr (PREC == kFp32) {
                         reinterpret_cast<float*>(A.vfeat)[e] = r;
                     } else {
                         reinterpret_cast<uint16_t*>(A.vfeat)[e] = toBits16<PREC>(r);
@@ -447,6 +511,9 @@ hipError_t launchHeadsBf16(const Args& a, hipStream_t s);
 hipError_t launchDenseFp32(const Args& a, hipStream_t s);
 hipError_t launchDenseFp16(const Args& a, hipStream_t s);
 hipError_t launchDenseBf16(const Args& a, hipStream_t s);
+hipError_t launchConvF16x3(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchHeadsF16x3(const Args& a, hipStream_t s);
+hipError_t launchDenseF16x3(const Args& a, hipStream_t s);
 
 } // namespace tile
 } // namespace nsg

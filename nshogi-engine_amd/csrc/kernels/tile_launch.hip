@@ -28,8 +28,8 @@ ConvPlan chooseConvPlan(int batch, int cout, int computeUnits) {
 
 hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
                          const void* residual, void* y, int batch, int cin,
-                         int cout, int relu, int prec, const ConvPlan& plan,
-                         hipStream_t stream) {
+                         int cout, int relu, float accScale, int prec,
+                         const ConvPlan& plan, hipStream_t stream) {
     if (batch <= 0 || (cin * elemSize(prec)) % 128 != 0 || cout % 64 != 0)
         return hipErrorInvalidValue;
     tile::Args a{};
@@ -42,10 +42,12 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
     a.cout = cout;
     a.totalRows = batch * 81;
     a.relu = relu;
+    a.accScale = accScale;
     switch (prec) {
     case kFp32: return tile::launchConvFp32(a, batch, plan, stream);
     case kFp16: return tile::launchConvFp16(a, batch, plan, stream);
     case kBf16: return tile::launchConvBf16(a, batch, plan, stream);
+    case kF16x3: return tile::launchConvF16x3(a, batch, plan, stream);
     }
     return hipErrorInvalidValue;
 }
@@ -53,7 +55,7 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
 hipError_t launchHeads(const void* x, const void* wfrag, const float* bias,
                        float* policy, void* vfeat, int batch, int channels,
                        int coutPadded, int valueChannels, int vfeatStride,
-                       int prec, hipStream_t stream) {
+                       float accScale, int prec, hipStream_t stream) {
     if (batch <= 0 || (channels * elemSize(prec)) % 128 != 0 || coutPadded % 64 != 0 ||
         valueChannels + 27 > coutPadded || vfeatStride < 81 * valueChannels)
         return hipErrorInvalidValue;
@@ -68,17 +70,19 @@ hipError_t launchHeads(const void* x, const void* wfrag, const float* bias,
     a.totalRows = batch * 81;
     a.valueChannels = valueChannels;
     a.vfeatStride = vfeatStride;
+    a.accScale = accScale;
     switch (prec) {
     case kFp32: return tile::launchHeadsFp32(a, stream);
     case kFp16: return tile::launchHeadsFp16(a, stream);
     case kBf16: return tile::launchHeadsBf16(a, stream);
+    case kF16x3: return tile::launchHeadsF16x3(a, stream);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launchDense(const void* x, const void* wfrag, const float* bias,
                        float* y, int rows, int kdim, int cout, int relu,
-                       int prec, hipStream_t stream) {
+                       float accScale, int prec, hipStream_t stream) {
     if (rows <= 0 || (kdim * elemSize(prec)) % 128 != 0 || cout % 64 != 0)
         return hipErrorInvalidValue;
     tile::Args a{};
@@ -90,10 +94,12 @@ hipError_t launchDense(const void* x, const void* wfrag, const float* bias,
     a.cout = cout;
     a.totalRows = rows;
     a.relu = relu;
+    a.accScale = accScale;
     switch (prec) {
     case kFp32: return tile::launchDenseFp32(a, stream);
     case kFp16: return tile::launchDenseFp16(a, stream);
     case kBf16: return tile::launchDenseBf16(a, stream);
+    case kF16x3: return tile::launchDenseF16x3(a, stream);
     }
     return hipErrorInvalidValue;
 }
@@ -142,9 +148,10 @@ hipError_t launchValueOut(const float* h, const float* w2, const float* b2,
 // Host-side weight packing.  Record (q, nf, lane) holds, for MFMA row
 // rho = lane & 15 and lane group g = lane >> 4 of output fragment nf:
 //   out channel n = (nf / 4) * 64 + (rho >> 2) * 16 + (nf % 4) * 4 + (rho & 3)
-//   slab        q = (kc*taps + tap)*2 + s
-//   f32 : 4 values, input channel kc*32 + s*16 + 4*g + i          (i = 0..3)
-//   16b : 8 values, input channel kc*64 + s*32 + 8*g + i          (i = 0..7)
+//   slab        q = (kc*taps + tap)*slabsPerTap + s
+//   f32  : 4 values, input channel kc*32 + s*16 + 4*g + i          (i = 0..3)
+//   16b  : 8 values, input channel kc*64 + s*32 + 8*g + i          (i = 0..7)
+//   f16x3: 8 values, input channel kc*32 + 8*g + i; s = 0: hi, 1: lo, 2: hi
 // Two zero slabs are appended so the kernel's two-slab-ahead prefetch never
 // reads past the allocation.
 // ---------------------------------------------------------------------------
@@ -164,21 +171,22 @@ static inline uint16_t hostF32ToBf16(float f) {
 
 size_t tileWeightRecords(int taps, int kdim, int cout, int prec) {
     const int nkc = kdim / chunkChannels(prec);
-    return ((size_t)nkc * taps * 2 + 2) * (cout / 16) * 64;
+    return ((size_t)nkc * taps * slabsPerTap(prec) + 2) * (cout / 16) * 64;
 }
 
 void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
-                     int kdim, int cout, int prec, void* dst) {
+                     int kdim, int cout, int prec, float scale, void* dst) {
     const int kcCh = chunkChannels(prec);
     const int nkc = kdim / kcCh;
     const int nft = cout / 16;
+    const int spt = slabsPerTap(prec);
     const int per = (prec == kFp32) ? 4 : 8; // values per record
     unsigned char* out = (unsigned char*)dst;
     memset(out, 0, tileWeightRecords(taps, kdim, cout, prec) * 16);
     for (int c = 0; c < nkc; ++c)
         for (int t = 0; t < taps; ++t)
-            for (int s = 0; s < 2; ++s) {
-                const size_t q = ((size_t)c * taps + t) * 2 + s;
+            for (int s = 0; s < spt; ++s) {
+                const size_t q = ((size_t)c * taps + t) * spt + s;
                 for (int nf = 0; nf < nft; ++nf)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int rho = lane & 15, g = lane >> 4;
@@ -186,10 +194,18 @@ void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
                                       (nf % kNfrag) * 4 + (rho & 3);
                         unsigned char* rec = out + ((q * nft + nf) * 64 + lane) * 16;
                         for (int i = 0; i < per; ++i) {
-                            const int k = c * kcCh + s * (kcCh / 2) + per * g + i;
-                            const float v = (k < kReal) ? get(ctx, n, k, t) : 0.f;
+                            // kF16x3: all three slabs cover the chunk's 32 channels
+                            const int k = (prec == kF16x3) ? c * kcCh + per * g + i
+                                                           : c * kcCh + s * (kcCh / 2) + per * g + i;
+                            const float v = (k < kReal) ? get(ctx, n, k, t) * scale : 0.f;
                             if (prec == kFp32) {
                                 memcpy(rec + i * 4, &v, 4);
+                            } else if (prec == kF16x3) {
+                                // slabs: (w_hi, x_hi) (w_lo, x_hi) (w_hi, x_lo)
+                                const _Float16 h = (_Float16)v;
+                                const _Float16 l = (_Float16)(v - (float)h);
+                                const _Float16 pick = (s == 1) ? l : h;
+                                memcpy(rec + i * 2, &pick, 2);
                             } else {
                                 const uint16_t hb = (prec == kFp16) ? hostF32ToF16(v) : hostF32ToBf16(v);
                                 memcpy(rec + i * 2, &hb, 2);

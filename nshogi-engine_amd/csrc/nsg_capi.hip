@@ -73,6 +73,7 @@ struct ConvLayer {
     DevBuf w;    // fragment-ordered weights
     DevBuf bias; // f32 [cout]
     int cin = 0; // padded input channels
+    float accScale = 1.f; // 1 / (power-of-two weight scale), kF16x3 only
 };
 
 // Parsed view of an NSGW v1 blob (DESIGN.md "Weight file").
@@ -228,10 +229,25 @@ int drainProfile(nsg_evaluator* ev) {
 }
 
 int uploadLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int kdim,
-                int cout, int prec, const std::vector<float>& bias, ConvLayer* L) {
+                int cout, int coutReal, int prec, const std::vector<float>& bias, ConvLayer* L) {
     const size_t bytes = nsg::tileWeightRecords(taps, kdim, cout, prec) * 16;
     std::vector<unsigned char> host(bytes);
-    nsg::packTileWeights(get, ctx, taps, kReal, kdim, cout, prec, host.data());
+    float scale = 1.f;
+    if (prec == nsg::kF16x3) {
+        // power-of-two scale putting the largest |w| in [2^8, 2^9): hi and lo of every
+        // weight that matters stay in f16's normal range; undone exactly by accScale
+        float maxAbs = 0.f;
+        for (int n = 0; n < coutReal; ++n)
+            for (int k = 0; k < kReal; ++k)
+                for (int t = 0; t < taps; ++t) maxAbs = std::fmax(maxAbs, std::fabs(get(ctx, n, k, t)));
+        if (maxAbs > 0.f && std::isfinite(maxAbs)) {
+            int e = 0;
+            std::frexp(maxAbs, &e); // maxAbs = m * 2^e, m in [0.5, 1)
+            scale = std::ldexp(1.0f, 9 - e);
+        }
+    }
+    L->accScale = 1.0f / scale;
+    nsg::packTileWeights(get, ctx, taps, kReal, kdim, cout, prec, scale, host.data());
     int rc = L->w.alloc(bytes, false);
     if (rc) return rc;
     NSG_HIP(hipMemcpy(L->w.p, host.data(), bytes, hipMemcpyHostToDevice));
@@ -268,13 +284,13 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     void* y = ev->act[1].p;
     void* z = ev->act[2].p;
     NSG_HIP(nsg::launchConv3x3(ev->planes.p, ev->stem.w.p, (const float*)ev->stem.bias.p,
-                               nullptr, x, B, ev->cpad, ev->F, 1, prec, plan, s));
+                               nullptr, x, B, ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s));
     if (prof) NSG_HIP(hipEventRecord(e[1], s));
     for (int k = 0; k < ev->blocks; ++k) {
         NSG_HIP(nsg::launchConv3x3(x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p,
-                                   nullptr, y, B, ev->F, ev->F, 1, prec, plan, s));
+                                   nullptr, y, B, ev->F, ev->F, 1, ev->conv1[k].accScale, prec, plan, s));
         NSG_HIP(nsg::launchConv3x3(y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p,
-                                   x, z, B, ev->F, ev->F, 1, prec, plan, s));
+                                   x, z, B, ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s));
         void* t = x; x = z; z = t;
     }
     if (prof) NSG_HIP(hipEventRecord(e[2], s));
@@ -282,9 +298,9 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // heads
     NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p,
                              (float*)ev->policy.p, ev->vfeat.p, B, ev->F, ev->headsCout,
-                             ev->vc, ev->fc1K, prec, s));
+                             ev->vc, ev->fc1K, ev->heads.accScale, prec, s));
     NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->fc1.w.p, (const float*)ev->fc1.bias.p,
-                             (float*)ev->hidden.p, B, ev->fc1K, ev->vh, 1, prec, s));
+                             (float*)ev->hidden.p, B, ev->fc1K, ev->vh, 1, ev->fc1.accScale, prec, s));
     NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->fc2W.p,
                                 (const float*)ev->fc2B.p, (float*)ev->value.p,
                                 (float*)ev->draw.p, B, ev->vh, s));
@@ -355,7 +371,7 @@ int nsg_destroy(nsg_evaluator* ev) {
 int nsg_set_precision(nsg_evaluator* ev, int precision) {
     if (!ev) return fail(NSG_E_INVALID, "null evaluator");
     if (ev->loaded) return fail(NSG_E_INVALID, "precision must be chosen before nsg_load");
-    if (precision < NSG_PRECISION_FP32 || precision > NSG_PRECISION_BF16)
+    if (precision < NSG_PRECISION_FP32 || precision > NSG_PRECISION_F16X3)
         return fail(NSG_E_INVALID, "unknown precision %d", precision);
     ev->prec = precision;
     return NSG_OK;
@@ -393,17 +409,17 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
     foldBn(nv.stemBn, nv.F, nv.eps, &scale, &bias);
     {
         Conv3Ctx c{nv.stemW, scale.data(), nv.cin};
-        if ((rc = uploadLayer(conv3Get, &c, 9, nv.cin, ev->cpad, nv.F, prec, bias, &ev->stem))) return rc;
+        if ((rc = uploadLayer(conv3Get, &c, 9, nv.cin, ev->cpad, nv.F, nv.F, prec, bias, &ev->stem))) return rc;
     }
     ev->conv1.clear(); ev->conv2.clear();
     ev->conv1.resize(nv.blocks); ev->conv2.resize(nv.blocks);
     for (int k = 0; k < nv.blocks; ++k) {
         foldBn(nv.bn1[k], nv.F, nv.eps, &scale, &bias);
         Conv3Ctx c1{nv.w1[k], scale.data(), nv.F};
-        if ((rc = uploadLayer(conv3Get, &c1, 9, nv.F, nv.F, nv.F, prec, bias, &ev->conv1[k]))) return rc;
+        if ((rc = uploadLayer(conv3Get, &c1, 9, nv.F, nv.F, nv.F, nv.F, prec, bias, &ev->conv1[k]))) return rc;
         foldBn(nv.bn2[k], nv.F, nv.eps, &scale, &bias);
         Conv3Ctx c2{nv.w2[k], scale.data(), nv.F};
-        if ((rc = uploadLayer(conv3Get, &c2, 9, nv.F, nv.F, nv.F, prec, bias, &ev->conv2[k]))) return rc;
+        if ((rc = uploadLayer(conv3Get, &c2, 9, nv.F, nv.F, nv.F, nv.F, prec, bias, &ev->conv2[k]))) return rc;
     }
     // heads: [value conv (BN folded) | policy conv | zero pad]
     {
@@ -412,12 +428,12 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
         for (int i = 0; i < nv.vc; ++i) hb[i] = bias[i];
         for (int i = 0; i < nv.pc; ++i) hb[nv.vc + i] = nv.polB[i];
         HeadsCtx c{nv.valW, scale.data(), nv.polW, nv.F, nv.vc, nv.pc};
-        if ((rc = uploadLayer(headsGet, &c, 1, nv.F, nv.F, ev->headsCout, prec, hb, &ev->heads))) return rc;
+        if ((rc = uploadLayer(headsGet, &c, 1, nv.F, nv.F, ev->headsCout, nv.vc + nv.pc, prec, hb, &ev->heads))) return rc;
     }
     {
         std::vector<float> b1(nv.fc1B, nv.fc1B + nv.vh);
         Fc1Ctx c{nv.fc1W, nv.vc};
-        if ((rc = uploadLayer(fc1Get, &c, 1, 81 * nv.vc, ev->fc1K, nv.vh, prec, b1, &ev->fc1))) return rc;
+        if ((rc = uploadLayer(fc1Get, &c, 1, 81 * nv.vc, ev->fc1K, nv.vh, nv.vh, prec, b1, &ev->fc1))) return rc;
     }
     if ((rc = ev->fc2W.alloc((size_t)2 * nv.vh * 4, false))) return rc;
     if ((rc = ev->fc2B.alloc(8, false))) return rc;

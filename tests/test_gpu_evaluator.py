@@ -137,10 +137,11 @@ def test_error_behaviour(nsg, tmp_path):
     assert ev2.info()["loaded"] == 1 and ev2.info()["channels"] == 64
 
 
-@pytest.mark.parametrize("precision,tol", [("fp16", 2e-2), ("bf16", 1.5e-1)])
+@pytest.mark.parametrize("precision,tol", [("f16x3", 1e-4), ("fp16", 2e-2), ("bf16", 1.5e-1)])
 def test_reduced_precision_paths(nsg, oracle, precision, tol):
-    """16-bit operand paths (f32 accumulate).  Their tolerance is looser than the
-    fp32 path's 1e-3 and is stated here; DESIGN.md discusses it."""
+    """16-bit operand paths (f32 accumulate).  f16x3 (split hi/lo, three MFMAs per
+    MAC) is f32-equivalent and is held to 1e-4; plain f16/bf16 are looser than the
+    north_star's 1e-3 and their tolerance is stated here; DESIGN.md discusses it."""
     ev, blob = make(nsg, 4, 128, 16, precision=precision, seed=5, bn="identity")
     bb = nsg.synth.random_batch(12, 86, seed=5)
     out = ev.compute_blocking(bb)
