@@ -30,6 +30,10 @@ class NsgError(RuntimeError):
 
 
 def library_path():
+    # NSG_LIB selects an alternate build (e.g. the diagnostic libnsg_diag.so)
+    override = os.environ.get("NSG_LIB")
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnsg.so")
 
 

@@ -57,7 +57,20 @@ inline int paddedBoards(int batch, int nb) { return (batch + nb - 1) / nb * nb; 
 hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
                          const void* residual, void* y, int batch, int cin,
                          int cout, int relu, float accScale, int prec,
-                         const ConvPlan& plan, hipStream_t stream);
+                         const ConvPlan& plan, hipStream_t stream, int ntStore = 0,
+                         unsigned long long* stamps = nullptr);
+
+// Persistent trunk: every 3x3 layer (stem + 2 per block) in ONE launch.  A layer
+// list is built once with trunkLayersBytes()/fillTrunkLayer() on the host, uploaded,
+// and reused for every batch size.  Needs cout == nwaves*64 (one workgroup covers all
+// output channels of its boards); canRunTrunk() says whether a plan qualifies.
+size_t trunkLayerBytes();
+void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfrag,
+                    const float* bias, const void* residual, void* y, int cin,
+                    int cout, int relu, float accScale, int ntStore);
+bool canRunTrunk(int cout, const ConvPlan& plan);
+hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
+                       const ConvPlan& plan, hipStream_t stream);
 
 // Policy 1x1 conv (27 ch, +bias, raw logits -> policy[b][c*81+sq] f32) and
 // value-feature 1x1 conv (VC ch, folded-BN bias, ReLU -> vfeat[b*vfeatStride + sq*VC+c] T)

@@ -159,20 +159,38 @@ struct Args {
     int valueChannels;        // kHeads: channels [0,VC) = value conv, [VC,VC+27) = policy
     int vfeatStride;          // kHeads: elements per board row of vfeat (>= 81*VC)
     float accScale;           // accumulators are multiplied by this before the bias (kF16x3: 1/weight scale)
+    int ntStore;              // reserved (non-temporal output stores measured no gain)
+    unsigned long long* stamps; // diagnostic builds only (NSG_DIAG_STAMPS): 8 u64 per workgroup
 };
+
+#ifdef NSG_DIAG_STAMPS
+#define NSG_STAMP(IDX)                                                                       \
+    do {                                                                                     \
+        if (A.stamps && threadIdx.x == 0) {                                                  \
+            A.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (IDX)] = __builtin_amdgcn_s_memtime(); \
+            if ((IDX) == 0) A.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
+            if ((IDX) == 3) A.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                    \
+    } while (0)
+#else
+#define NSG_STAMP(IDX) do { } while (0)
+#endif
 
 // Single-board conv tiles are small enough for two workgroups per CU (two waves
 // per SIMD): the second argument caps registers at 256 so both fit.
 template <int MODE, int SIZE, int NWAVES>
 constexpr int minWavesPerSimd() { return (MODE == kConv && SIZE == 1 && NWAVES >= 3) ? 2 : 1; }
 
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES>
-__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>())) void tileKernel(const Args A) {
+// One layer's work for this workgroup.  RES: 0 = no residual, 1 = residual,
+// 2 = decided at run time by A.res (persistent trunk kernel).
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES>
+__device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
     using G = Geom<MODE, SIZE, NWAVES>;
+    const bool hasRes = (RES == 1) || (RES == 2 && A.res != nullptr);
+    NSG_STAMP(0);
     constexpr int ES = (PREC == kFp32 || PREC == kF16x3) ? 4 : 2;
     constexpr bool kSplit = (PREC == kF16x3);
     static_assert(!kSplit || NFRAG == 4, "kF16x3 epilogue assumes 16 channels per lane");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -186,7 +204,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
     // kConv buffers are sized for whole workgroups; flat modes clamp rows.
     const size_t lastRow = G::kBoards ? ~(size_t)0 : (size_t)(A.totalRows - 1);
 
-    if constexpr (G::kBoards) {
+    if (G::kBoards && zeroLds) {
         // zero the LDS image: halo entries stay zero for the whole kernel
         for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
             reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -274,6 +292,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
     NSG_STAGE_WRITE(0)
     __syncthreads();
 
+    NSG_STAMP(1);
     u32x4 a[2][G::kMF]; // row fragments: current slab / next slab
     for (int kc = 0; kc < nkc; ++kc) {
         const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
@@ -323,6 +342,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
 
 #undef NSG_STAGE_LOAD
 #undef NSG_STAGE_WRITE
+    NSG_STAMP(2);
 
     // ---- epilogue.  Lane (li, g) holds, for fragment j, channels
     // cbase + 4j + {0..3} of row f*16 + li.
@@ -330,6 +350,146 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
     float bv[NFRAG * 4];
 #pragma unroll
     for (int i = 0; i < NFRAG * 4; ++i) bv[i] = A.bias[cbase + i];
+
+    if constexpr (MODE == kConv) {
+        // ---- convolution epilogue, staged through LDS so that every global access is
+        // a full-line, lane-linear 16-byte access.  In the MFMA result layout a lane
+        // owns 16 channels of ONE row, so a direct store scatters 16-byte pieces over
+        // 16 rows per instruction (measured: ~25 us of a 110 us layer).  Instead each
+        // wave builds the memory image of its 64-channel slice of 16 rows per fragment
+        // in a private LDS region (the input buffers are free after the last chunk's
+        // barrier), then moves it with lane l <-> piece l of the row-major image.
+        constexpr int kRowB = NFRAG * 16 * ES;      // this wave's bytes per row: 256 or 128
+        constexpr int kRowS = kRowB + 16;           // padded LDS row stride
+        constexpr int kNP = kRowB / 64;             // 16-byte pieces per lane: 4 or 2
+        constexpr int kPPR = kRowB / 16;            // pieces per row: 16 or 8
+        constexpr int kRPI = 64 / kPPR;             // rows per wave instruction: 4 or 8
+        constexpr int kIPF = 16 / kRPI;             // instructions per 16-row fragment
+        constexpr int kFragBytes = 16 * kRowS;
+        constexpr int kFPB = (G::kLds / NWAVES / kFragBytes) < 1 ? 1
+                           : ((G::kLds / NWAVES / kFragBytes) > G::kMF ? G::kMF : (G::kLds / NWAVES / kFragBytes));
+        static_assert(kFragBytes <= G::kLds / NWAVES, "epilogue staging does not fit");
+        unsigned char* ebuf = smem + wave * (G::kLds / NWAVES);
+        const size_t rowBytes = (size_t)A.cout * ES;
+        const size_t sliceOff = (size_t)waveGroup * kRowB;
+        // byte offset, inside the row slice, of this lane's k-th 16-byte piece
+        auto pieceOff = [&](int k) -> int {
+            if constexpr (kSplit) return (g >> 1) * 128 + (g & 1) * 32 + (k & 1) * 16 + (k >> 1) * 64;
+            else return g * (kRowB / 4) + k * 16;
+        };
+        const int lrow = lane / kPPR;   // lane-linear view: row within an instruction
+        const int lpc = lane % kPPR;    //                   piece within the row
+
+#pragma unroll
+        for (int f0 = 0; f0 < G::kMF; f0 += kFPB) {
+            if (hasRes) {
+                // residual: global (lane-linear, full lines) -> LDS image
+#pragma unroll
+                for (int ff = 0; ff < kFPB; ++ff) {
+                    if (f0 + ff < G::kMF) {
+#pragma unroll
+                        for (int it = 0; it < kIPF; ++it) {
+                            const int r = it * kRPI + lrow;
+                            const int m = (f0 + ff) * 16 + r;
+                            u32x4 t = u32x4{0u, 0u, 0u, 0u};
+                            if (m < G::kRows)
+                                t = *reinterpret_cast<const u32x4*>(A.res + (row0 + m) * rowBytes + sliceOff + lpc * 16);
+                            *reinterpret_cast<u32x4*>(ebuf + ff * kFragBytes + r * kRowS + lpc * 16) = t;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int ff = 0; ff < kFPB; ++ff) {
+                const int f = f0 + ff;
+                if (f < G::kMF) {
+                    float v[NFRAG * 4];
+#pragma unroll
+                    for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaf(acc[f][j][r], A.accScale, bv[j * 4 + r]);
+                    unsigned char* lrowp = ebuf + ff * kFragBytes + li * kRowS;
+                    if (hasRes) {
+                        u32x4 rp[kNP];
+#pragma unroll
+                        for (int k = 0; k < kNP; ++k) rp[k] = *reinterpret_cast<const u32x4*>(lrowp + pieceOff(k));
+                        if constexpr (PREC == kFp32) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[k * 4 + i] += __uint_as_float(rp[k][i]);
+                        } else if constexpr (kSplit) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    v[k * 8 + 2 * i] += f16BitsToF32((uint16_t)(rp[k][i] & 0xffffu)) +
+                                                        f16BitsToF32((uint16_t)(rp[2 + k][i] & 0xffffu));
+                                    v[k * 8 + 2 * i + 1] += f16BitsToF32((uint16_t)(rp[k][i] >> 16)) +
+                                                            f16BitsToF32((uint16_t)(rp[2 + k][i] >> 16));
+                                }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    v[k * 8 + 2 * i] += unpackLo<PREC>(rp[k][i]);
+                                    v[k * 8 + 2 * i + 1] += unpackHi<PREC>(rp[k][i]);
+                                }
+                        }
+                    }
+                    if (A.relu) {
+#pragma unroll
+                        for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    }
+                    u32x4 op[kNP];
+                    if constexpr (PREC == kFp32) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) op[k][i] = __float_as_uint(v[k * 4 + i]);
+                    } else if constexpr (kSplit) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                uint16_t h0, l0, h1, l1;
+                                splitF16(v[k * 8 + 2 * i], h0, l0);
+                                splitF16(v[k * 8 + 2 * i + 1], h1, l1);
+                                op[k][i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                                op[2 + k][i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                            }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) op[k][i] = packPair<PREC>(v[k * 8 + 2 * i], v[k * 8 + 2 * i + 1]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < kNP; ++k) *reinterpret_cast<u32x4*>(lrowp + pieceOff(k)) = op[k];
+                }
+            }
+            // LDS image -> global, lane-linear: kRPI rows x kRowB contiguous bytes per instruction
+#pragma unroll
+            for (int ff = 0; ff < kFPB; ++ff) {
+                if (f0 + ff < G::kMF) {
+#pragma unroll
+                    for (int it = 0; it < kIPF; ++it) {
+                        const int r = it * kRPI + lrow;
+                        const int m = (f0 + ff) * 16 + r;
+                        const u32x4 t = *reinterpret_cast<const u32x4*>(ebuf + ff * kFragBytes + r * kRowS + lpc * 16);
+                        if (m < G::kRows)
+                            *reinterpret_cast<u32x4*>(A.y + (row0 + m) * rowBytes + sliceOff + lpc * 16) = t;
+                    }
+                }
+            }
+        }
+#ifdef NSG_DIAG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stamp 3 = own stores issued and acknowledged
+#endif
+        NSG_STAMP(3);
+        return;
+    }
 
 #pragma unroll
     for (int f = 0; f < G::kMF; ++f) {
@@ -343,81 +503,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaf(acc[f][j][r], A.accScale, bv[j * 4 + r]);
 
-        if constexpr (MODE == kConv && kSplit) {
-            // row layout: 128-byte chunks of 32 channels = [32 x f16 hi][32 x f16 lo];
-            // this lane's 16 channels are 32 contiguous hi bytes and 32 contiguous lo bytes
-            const size_t e = grow * (size_t)A.cout * 4 + (size_t)(cbase >> 5) * 128 + (cbase & 31) * 2;
-            if constexpr (HAS_RES) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32x4 rh = *reinterpret_cast<const u32x4*>(A.res + e + h * 16);
-                    const u32x4 rl = *reinterpret_cast<const u32x4*>(A.res + e + 64 + h * 16);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[h * 8 + 2 * i] += f16BitsToF32((uint16_t)(rh[i] & 0xffffu)) + f16BitsToF32((uint16_t)(rl[i] & 0xffffu));
-                        v[h * 8 + 2 * i + 1] += f16BitsToF32((uint16_t)(rh[i] >> 16)) + f16BitsToF32((uint16_t)(rl[i] >> 16));
-                    }
-                }
-            }
-            if (A.relu) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
-            }
-            uint16_t hb[16], lb[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) splitF16(v[i], hb[i], lb[i]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                u32x4 oh, ol;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    oh[i] = (uint32_t)hb[h * 8 + 2 * i] | ((uint32_t)hb[h * 8 + 2 * i + 1] << 16);
-                    ol[i] = (uint32_t)lb[h * 8 + 2 * i] | ((uint32_t)lb[h * 8 + 2 * i + 1] << 16);
-                }
-                *reinterpret_cast<u32x4*>(A.y + e + h * 16) = oh;
-                *reinterpret_cast<u32x4*>(A.y + e + 64 + h * 16) = ol;
-            }
-        } else         if constexpr (MODE == kConv) {
-            const size_t e = (grow * (size_t)A.cout + cbase) * ES;
-            if constexpr (HAS_RES) {
-                if constexpr (PREC == kFp32) {
-#pragma unroll
-                    for (int j = 0; j < NFRAG; ++j) {
-                        const f32x4 rr = *reinterpret_cast<const f32x4*>(A.res + e + j * 16);
-                        v[j * 4 + 0] += rr.x; v[j * 4 + 1] += rr.y;
-                        v[j * 4 + 2] += rr.z; v[j * 4 + 3] += rr.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NFRAG; ++j) {
-                        const u32x2 rr = *reinterpret_cast<const u32x2*>(A.res + e + j * 8);
-                        v[j * 4 + 0] += unpackLo<PREC>(rr.x); v[j * 4 + 1] += unpackHi<PREC>(rr.x);
-                        v[j * 4 + 2] += unpackLo<PREC>(rr.y); v[j * 4 + 3] += unpackHi<PREC>(rr.y);
-                    }
-                }
-            }
-            if (A.relu) {
-#pragma unroll
-                for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
-            }
-            if constexpr (PREC == kFp32) {
-#pragma unroll
-                for (int j = 0; j < NFRAG; ++j)
-                    *reinterpret_cast<f32x4*>(A.y + e + j * 16) =
-                        f32x4{v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
-            } else if constexpr (NFRAG % 2 == 0) {
-#pragma unroll
-                for (int j = 0; j < NFRAG; j += 2)
-                    *reinterpret_cast<u32x4*>(A.y + e + j * 8) = u32x4{
-                        packPair<PREC>(v[j * 4], v[j * 4 + 1]), packPair<PREC>(v[j * 4 + 2], v[j * 4 + 3]),
-                        packPair<PREC>(v[j * 4 + 4], v[j * 4 + 5]), packPair<PREC>(v[j * 4 + 6], v[j * 4 + 7])};
-            } else {
-#pragma unroll
-                for (int j = 0; j < NFRAG; ++j)
-                    *reinterpret_cast<u32x2*>(A.y + e + j * 8) = u32x2{
-                        packPair<PREC>(v[j * 4], v[j * 4 + 1]), packPair<PREC>(v[j * 4 + 2], v[j * 4 + 3])};
-            }
-        } else if constexpr (MODE == kHeads) {
+        if constexpr (MODE == kHeads) {
             const int b = (int)(grow / 81);
             const int sq = (int)(grow - (size_t)b * 81);
             const int vc = A.valueChannels;
@@ -458,6 +544,31 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>()
     }
 }
 
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES>
+__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>())) void tileKernel(const Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0>(A, smem, true);
+}
+
+// Persistent trunk: one launch runs every 3x3 layer (stem + 2 per residual block)
+// for this workgroup's boards.  A workgroup owns whole boards, so layer l+1 needs
+// only what this same workgroup wrote in layer l: there is NO inter-workgroup
+// dependency, hence no grid barrier, no residency requirement and no launch
+// boundary between layers.  Workgroups drift apart freely instead of being
+// re-synchronised 2N+1 times per forward.
+template <int PREC, int SIZE, int NFRAG, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES>())) void trunkKernel(
+    const Args* __restrict__ layers, int nLayers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    for (int l = 0; l < nLayers; ++l) {
+        const Args A = layers[l];
+        tileBody<PREC, kConv, SIZE, NFRAG, NWAVES, 2>(A, smem, true); // the epilogue staging reuses the halo entries: re-zero
+        // this layer's stores (all waves) land before any wave stages them as the
+        // next layer's input: vmcnt(0) + workgroup barrier (same CU, same L1/L2 path)
+        __syncthreads();
+    }
+}
+
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES>
 hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
     using G = Geom<MODE, SIZE, NWAVES>;
@@ -478,7 +589,26 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int PREC, int SIZE, int NFRAG, int NWAVES>
+hipError_t launchTrunkOne(const Args* layers, int nLayers, int gridX, hipStream_t stream) {
+    using G = Geom<kConv, SIZE, NWAVES>;
+    auto k = trunkKernel<PREC, SIZE, NFRAG, NWAVES>;
+    hipError_t err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k, dim3(gridX, 1), dim3(G::kThreads), G::kLdsAlloc, stream, layers, nLayers);
+    return hipGetLastError();
+}
+
 // Per-precision entry points (one translation unit each).
+template <int PREC>
+hipError_t launchTrunkPrec(const Args* layers, int nLayers, int batch, const ConvPlan& p, hipStream_t stream) {
+    const int gx = (batch + p.nb - 1) / p.nb;
+#define NSG_CASE(NB_, NW_) \
+    if (p.nb == NB_ && p.nfrag == 4 && p.nwaves == NW_) return launchTrunkOne<PREC, NB_, 4, NW_>(layers, nLayers, gx, stream);
+    NSG_CASE(2, 4) NSG_CASE(2, 3) NSG_CASE(1, 4) NSG_CASE(1, 3)
+#undef NSG_CASE
+    return hipErrorInvalidValue;
+}
 template <int PREC>
 hipError_t launchConvPrec(const Args& a, int batch, const ConvPlan& p, hipStream_t stream) {
     const int gx = (batch + p.nb - 1) / p.nb;
@@ -512,6 +642,10 @@ hipError_t launchDenseFp32(const Args& a, hipStream_t s);
 hipError_t launchDenseFp16(const Args& a, hipStream_t s);
 hipError_t launchDenseBf16(const Args& a, hipStream_t s);
 hipError_t launchConvF16x3(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchTrunkFp32(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchTrunkFp16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchTrunkBf16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchTrunkF16x3(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchHeadsF16x3(const Args& a, hipStream_t s);
 hipError_t launchDenseF16x3(const Args& a, hipStream_t s);
 

@@ -8,6 +8,9 @@ namespace tile {
 hipError_t launchConvF16x3(const Args& a, int batch, const ConvPlan& p, hipStream_t s) {
     return launchConvPrec<kF16x3>(a, batch, p, s);
 }
+hipError_t launchTrunkF16x3(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s) {
+    return launchTrunkPrec<kF16x3>(layers, n, batch, p, s);
+}
 hipError_t launchHeadsF16x3(const Args& a, hipStream_t s) { return launchHeadsPrec<kF16x3>(a, s); }
 hipError_t launchDenseF16x3(const Args& a, hipStream_t s) { return launchDensePrec<kF16x3>(a, s); }
 

@@ -29,7 +29,8 @@ ConvPlan chooseConvPlan(int batch, int cout, int computeUnits) {
 hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
                          const void* residual, void* y, int batch, int cin,
                          int cout, int relu, float accScale, int prec,
-                         const ConvPlan& plan, hipStream_t stream) {
+                         const ConvPlan& plan, hipStream_t stream, int ntStore,
+                         unsigned long long* stamps) {
     if (batch <= 0 || (cin * elemSize(prec)) % 128 != 0 || cout % 64 != 0)
         return hipErrorInvalidValue;
     tile::Args a{};
@@ -43,11 +44,49 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
     a.totalRows = batch * 81;
     a.relu = relu;
     a.accScale = accScale;
+    a.ntStore = ntStore;
+    a.stamps = stamps;
     switch (prec) {
     case kFp32: return tile::launchConvFp32(a, batch, plan, stream);
     case kFp16: return tile::launchConvFp16(a, batch, plan, stream);
     case kBf16: return tile::launchConvBf16(a, batch, plan, stream);
     case kF16x3: return tile::launchConvF16x3(a, batch, plan, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+size_t trunkLayerBytes() { return sizeof(tile::Args); }
+
+void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfrag,
+                    const float* bias, const void* residual, void* y, int cin,
+                    int cout, int relu, float accScale, int ntStore) {
+    tile::Args a{};
+    a.ntStore = ntStore;
+    a.x = (const unsigned char*)x;
+    a.w = (const tile::u32x4*)wfrag;
+    a.bias = bias;
+    a.res = (const unsigned char*)residual;
+    a.y = (unsigned char*)y;
+    a.kdim = cin;
+    a.cout = cout;
+    a.relu = relu;
+    a.accScale = accScale;
+    memcpy((unsigned char*)hostLayers + (size_t)index * sizeof(tile::Args), &a, sizeof(a));
+}
+
+bool canRunTrunk(int cout, const ConvPlan& plan) {
+    return plan.nfrag == 4 && cout == plan.nwaves * 64 && (plan.nwaves == 4 || plan.nwaves == 3);
+}
+
+hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
+                       const ConvPlan& plan, hipStream_t stream) {
+    if (batch <= 0 || nLayers <= 0) return hipErrorInvalidValue;
+    const tile::Args* L = (const tile::Args*)devLayers;
+    switch (prec) {
+    case kFp32: return tile::launchTrunkFp32(L, nLayers, batch, plan, stream);
+    case kFp16: return tile::launchTrunkFp16(L, nLayers, batch, plan, stream);
+    case kBf16: return tile::launchTrunkBf16(L, nLayers, batch, plan, stream);
+    case kF16x3: return tile::launchTrunkF16x3(L, nLayers, batch, plan, stream);
     }
     return hipErrorInvalidValue;
 }

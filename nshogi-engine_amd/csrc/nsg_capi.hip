@@ -193,6 +193,11 @@ struct nsg_evaluator {
     ConvLayer heads;
     ConvLayer fc1;
     DevBuf fc2W, fc2B;
+    DevBuf stamps;           // diagnostic builds: per-layer, per-workgroup cycle stamps
+    DevBuf trunkLayers;      // persistent-trunk layer list (stem + 2 per block)
+    int trunkLayerCount = 0;
+    bool useTrunkKernel = false; // NSG_TRUNK_KERNEL=1: one persistent launch for all 3x3 layers (measured slower)
+    int ntStore = 0;             // NSG_NT_STORE=1: non-temporal activation stores (experiment)
 
     void* trunkOut = nullptr; // which act[] holds the trunk output of the last forward
 
@@ -279,19 +284,34 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // feature planes (replaces cuda::extractBits, trt.cc:255-258)
     NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, B,
                                       ev->numChannels, ev->cpad, prec, s));
-    // stem
+    // stem + residual trunk
     void* x = ev->act[0].p;
     void* y = ev->act[1].p;
     void* z = ev->act[2].p;
-    NSG_HIP(nsg::launchConv3x3(ev->planes.p, ev->stem.w.p, (const float*)ev->stem.bias.p,
-                               nullptr, x, B, ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s));
-    if (prof) NSG_HIP(hipEventRecord(e[1], s));
-    for (int k = 0; k < ev->blocks; ++k) {
-        NSG_HIP(nsg::launchConv3x3(x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p,
-                                   nullptr, y, B, ev->F, ev->F, 1, ev->conv1[k].accScale, prec, plan, s));
-        NSG_HIP(nsg::launchConv3x3(y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p,
-                                   x, z, B, ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s));
-        void* t = x; x = z; z = t;
+    if (ev->useTrunkKernel && nsg::canRunTrunk(ev->F, plan)) {
+        // one persistent launch for all 2N+1 3x3 layers (buffers rotate as below)
+        if (prof) NSG_HIP(hipEventRecord(e[1], s));
+        NSG_HIP(nsg::launchTrunk(ev->trunkLayers.p, ev->trunkLayerCount, B, prec, plan, s));
+        if (ev->blocks % 2 == 1) x = z; // the output buffer alternates act[0] / act[2]
+    } else {
+        NSG_HIP(nsg::launchConv3x3(ev->planes.p, ev->stem.w.p, (const float*)ev->stem.bias.p,
+                                   nullptr, x, B, ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s, ev->ntStore));
+        if (prof) NSG_HIP(hipEventRecord(e[1], s));
+        for (int k = 0; k < ev->blocks; ++k) {
+            unsigned long long* st1 = nullptr;
+            unsigned long long* st2 = nullptr;
+#ifdef NSG_DIAG_STAMPS
+            if (ev->stamps.p) {
+                st1 = (unsigned long long*)ev->stamps.p + (size_t)(2 * k) * 4096 * 8;
+                st2 = (unsigned long long*)ev->stamps.p + (size_t)(2 * k + 1) * 4096 * 8;
+            }
+#endif
+            NSG_HIP(nsg::launchConv3x3(x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p,
+                                       nullptr, y, B, ev->F, ev->F, 1, ev->conv1[k].accScale, prec, plan, s, ev->ntStore, st1));
+            NSG_HIP(nsg::launchConv3x3(y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p,
+                                       x, z, B, ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s, ev->ntStore, st2));
+            void* t = x; x = z; z = t;
+        }
     }
     if (prof) NSG_HIP(hipEventRecord(e[2], s));
     ev->trunkOut = x;
@@ -307,7 +327,7 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     if (prof) {
         NSG_HIP(hipEventRecord(e[3], s));
         ev->evUsed += 4;
-        ev->pendingTrunkLaunchesPerFwd = 2 * ev->blocks;
+        ev->pendingTrunkLaunchesPerFwd = 2 * ev->blocks; // conv layers bracketed by e[1]..e[2]
     }
     return NSG_OK;
 }
@@ -447,6 +467,28 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
         if ((rc = ev->act[i].alloc(bpad * 81 * nv.F * es, true))) return rc;
     if ((rc = ev->vfeat.alloc((size_t)ev->batchMax * ev->fc1K * es, true))) return rc;
     if ((rc = ev->hidden.alloc((size_t)ev->batchMax * nv.vh * 4, true))) return rc;
+    {   // persistent-trunk layer list, same buffer rotation as the per-layer path
+        const char* envNt = getenv("NSG_NT_STORE");
+        ev->ntStore = (envNt && envNt[0] == '1') ? 1 : 0;
+        const int nt = ev->ntStore;
+        const int nl = 1 + 2 * nv.blocks;
+        std::vector<unsigned char> host((size_t)nl * nsg::trunkLayerBytes());
+        void* x = ev->act[0].p; void* y = ev->act[1].p; void* z = ev->act[2].p;
+        nsg::fillTrunkLayer(host.data(), 0, ev->planes.p, ev->stem.w.p, (const float*)ev->stem.bias.p,
+                            nullptr, x, ev->cpad, nv.F, 1, ev->stem.accScale, nt);
+        for (int k = 0; k < nv.blocks; ++k) {
+            nsg::fillTrunkLayer(host.data(), 1 + 2 * k, x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p,
+                                nullptr, y, nv.F, nv.F, 1, ev->conv1[k].accScale, nt);
+            nsg::fillTrunkLayer(host.data(), 2 + 2 * k, y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p,
+                                x, z, nv.F, nv.F, 1, ev->conv2[k].accScale, nt);
+            void* t = x; x = z; z = t;
+        }
+        if ((rc = ev->trunkLayers.alloc(host.size(), false))) return rc;
+        NSG_HIP(hipMemcpy(ev->trunkLayers.p, host.data(), host.size(), hipMemcpyHostToDevice));
+        ev->trunkLayerCount = nl;
+        const char* env = getenv("NSG_TRUNK_KERNEL");
+        ev->useTrunkKernel = (env && env[0] == '1');
+    }
     NSG_HIP(hipDeviceSynchronize());
     ev->loaded = true;
     return NSG_OK;
@@ -647,6 +689,22 @@ int nsg_get_info(nsg_evaluator* ev, nsg_info* info) {
     snprintf(info->device_name, sizeof(info->device_name), "%s", ev->prop.name);
     return NSG_OK;
 }
+
+#ifdef NSG_DIAG_STAMPS
+// Diagnostic library only (make diag): cycle stamps of every trunk-conv workgroup.
+// layout: [layer][4096 workgroups][8 u64] = entry, prologue done, main loop done,
+// epilogue done (s_memtime), -, -, s_memrealtime at epilogue done / at entry.
+int nsg_debug_stamps_enable(nsg_evaluator* ev) {
+    if (!ev || !ev->loaded) return fail(NSG_E_INVALID, "load first");
+    return ev->stamps.alloc((size_t)2 * ev->blocks * 4096 * 8 * 8, true);
+}
+int nsg_debug_stamps_read(nsg_evaluator* ev, unsigned long long* dst) {
+    if (!ev || !ev->stamps.p) return fail(NSG_E_INVALID, "stamps not enabled");
+    NSG_HIP(hipDeviceSynchronize());
+    NSG_HIP(hipMemcpy(dst, ev->stamps.p, ev->stamps.bytes, hipMemcpyDeviceToHost));
+    return NSG_OK;
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // CPU stand-in executors (src/infer/zero.cc, nothing.cc, random.cc).
