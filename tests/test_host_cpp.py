@@ -80,3 +80,28 @@ def test_batchsize_bench_runs(nsg, tmp_path):
     rows = [ln.split(",") for ln in r.stdout.strip().split("\n")[1:]]
     assert [int(x[0]) for x in rows] == [60, 61, 62]
     assert all(float(x[2]) > 0 for x in rows)
+
+
+@pytest.mark.parametrize("cfg", ["5000 4 64 4 2 2", "3000 8 7 3 1 0", "2000 1 512 3 2 4", "8000 6 33 5 3 3"])
+def test_batch_pipeline_routing_cpu(cfg):
+    """evaluate::BatchPipeline (a9/a10) under concurrency with a checksum executor:
+    every leaf is fed exactly once with the outputs computed from its own features."""
+    _build()
+    r = subprocess.run([os.path.join(HOST, "pipeline_test"), "checksum"] + cfg.split(),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "missing 0 dup 0 wrong 0" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["3000 4 64 4 2 2", "1500 3 17 3 1 1"])
+def test_batch_pipeline_hip_bit_identical(nsg, tmp_path, cfg):
+    """Pipelined (double-buffered, direct-to-pinned) results are bit-identical to the
+    plain blocking Evaluator path for every leaf."""
+    _build()
+    path = tmp_path / "net.nsgw"
+    nsg.weights.save(str(path), nsg.weights.make_random(2, 64, seed=5, bn="random"))
+    r = subprocess.run([os.path.join(HOST, "pipeline_test"), "hip"] + cfg.split() + [str(path)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "missing 0 dup 0 wrong 0" in r.stdout
