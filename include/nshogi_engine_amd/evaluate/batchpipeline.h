@@ -98,6 +98,7 @@ class BatchPipeline {
 
     ~BatchPipeline() {
         close();
+        stopFeeders();
         for (auto& T : Feeders) {
             T.join();
         }
@@ -192,6 +193,7 @@ class BatchPipeline {
                     retire(Flying.front());
                     Flying.pop_front();
                 }
+                stopFeeders(); // after the last batch has been handed over
                 return;
             }
             if (!Flying.empty()) {
@@ -212,11 +214,6 @@ class BatchPipeline {
         }
         ProducerCV.notify_all();
         EvalCV.notify_all();
-        {
-            std::lock_guard<std::mutex> Lock(FeedMutex);
-            FeedClosed = true;
-        }
-        FeedCV.notify_all();
     }
 
     Stats stats() const {
@@ -255,6 +252,15 @@ class BatchPipeline {
         std::size_t Begin;
         std::size_t End;
     };
+
+    // Feed threads drain every queued job before they exit.
+    void stopFeeders() {
+        {
+            std::lock_guard<std::mutex> Lock(FeedMutex);
+            FeedClosed = true;
+        }
+        FeedCV.notify_all();
+    }
 
     void wakeEvaluator() {
         EvalCV.notify_one();
