@@ -190,7 +190,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     NSG_STAMP(0);
     constexpr int ES = (PREC == kFp32 || PREC == kF16x3) ? 4 : 2;
     constexpr bool kSplit = (PREC == kF16x3);
-    static_assert(!kSplit || NFRAG == 4, "kF16x3 epilogue assumes 16 channels per lane");
+    static_assert(NFRAG == 1 || NFRAG == 2 || NFRAG == 4, "fragments per wave");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -346,12 +346,96 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 
     // ---- epilogue.  Lane (li, g) holds, for fragment j, channels
     // cbase + 4j + {0..3} of row f*16 + li.
-    const int cbase = waveGroup * NFRAG * 16 + g * 4 * NFRAG;
+    // (weights are packed in groups of kNfrag = 4 fragments = 64 channels: fragment
+    // nf, MFMA row 4g+r  <->  channel (nf/4)*64 + g*16 + (nf%4)*4 + r; a wave that runs
+    // NFRAG < 4 fragments owns 4*NFRAG consecutive channels inside such a group)
+    const int nf0 = waveGroup * NFRAG;
+    const int cbase = (nf0 >> 2) * 64 + g * 16 + (nf0 & 3) * 4;
     float bv[NFRAG * 4];
 #pragma unroll
     for (int i = 0; i < NFRAG * 4; ++i) bv[i] = A.bias[cbase + i];
 
-    if constexpr (MODE == kConv) {
+    if constexpr (MODE == kConv && NFRAG < 4) {
+        // ---- small-batch tiles (1 or 2 fragments per wave): direct stores from the
+        // MFMA layout; these launches are latency-bound, not bandwidth-bound.
+#pragma unroll
+        for (int f = 0; f < G::kMF; ++f) {
+            const int m = f * 16 + li;
+            if (m >= G::kRows) continue;
+            const size_t grow = row0 + m;
+            float v[NFRAG * 4];
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaf(acc[f][j][r], A.accScale, bv[j * 4 + r]);
+            if constexpr (kSplit) {
+                const size_t e = grow * (size_t)A.cout * 4 + (size_t)(cbase >> 5) * 128 + (cbase & 31) * 2;
+                if (hasRes) {
+#pragma unroll
+                    for (int j = 0; j < NFRAG; ++j) {
+                        const u32x2 rh = *reinterpret_cast<const u32x2*>(A.res + e + j * 8);
+                        const u32x2 rl = *reinterpret_cast<const u32x2*>(A.res + e + 64 + j * 8);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            v[j * 4 + 2 * i] += f16BitsToF32((uint16_t)(rh[i] & 0xffffu)) + f16BitsToF32((uint16_t)(rl[i] & 0xffffu));
+                            v[j * 4 + 2 * i + 1] += f16BitsToF32((uint16_t)(rh[i] >> 16)) + f16BitsToF32((uint16_t)(rl[i] >> 16));
+                        }
+                    }
+                }
+                if (A.relu) {
+#pragma unroll
+                    for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) {
+                    u32x2 oh, ol;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        uint16_t h0, l0, h1, l1;
+                        splitF16(v[j * 4 + 2 * i], h0, l0);
+                        splitF16(v[j * 4 + 2 * i + 1], h1, l1);
+                        oh[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                        ol[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                    }
+                    *reinterpret_cast<u32x2*>(A.y + e + j * 8) = oh;
+                    *reinterpret_cast<u32x2*>(A.y + e + 64 + j * 8) = ol;
+                }
+            } else {
+                const size_t e = (grow * (size_t)A.cout + cbase) * ES;
+                if (hasRes) {
+#pragma unroll
+                    for (int j = 0; j < NFRAG; ++j) {
+                        if constexpr (PREC == kFp32) {
+                            const f32x4 rr = *reinterpret_cast<const f32x4*>(A.res + e + j * 16);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[j * 4 + i] += rr[i];
+                        } else {
+                            const u32x2 rr = *reinterpret_cast<const u32x2*>(A.res + e + j * 8);
+                            v[j * 4 + 0] += unpackLo<PREC>(rr.x); v[j * 4 + 1] += unpackHi<PREC>(rr.x);
+                            v[j * 4 + 2] += unpackLo<PREC>(rr.y); v[j * 4 + 3] += unpackHi<PREC>(rr.y);
+                        }
+                    }
+                }
+                if (A.relu) {
+#pragma unroll
+                    for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) {
+                    if constexpr (PREC == kFp32) {
+                        *reinterpret_cast<f32x4*>(A.y + e + j * 16) = f32x4{v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
+                    } else {
+                        *reinterpret_cast<u32x2*>(A.y + e + j * 8) =
+                            u32x2{packPair<PREC>(v[j * 4], v[j * 4 + 1]), packPair<PREC>(v[j * 4 + 2], v[j * 4 + 3])};
+                    }
+                }
+            }
+        }
+        NSG_STAMP(3);
+        return;
+    }
+
+    if constexpr (MODE == kConv && NFRAG == 4) {
         // ---- convolution epilogue, staged through LDS so that every global access is
         // a full-line, lane-linear 16-byte access.  In the MFMA result layout a lane
         // owns 16 channels of ONE row, so a direct store scatters 16-byte pieces over
@@ -612,10 +696,12 @@ hipError_t launchTrunkPrec(const Args* layers, int nLayers, int batch, const Con
 template <int PREC>
 hipError_t launchConvPrec(const Args& a, int batch, const ConvPlan& p, hipStream_t stream) {
     const int gx = (batch + p.nb - 1) / p.nb;
-#define NSG_CASE(NB_, NW_) \
-    if (p.nb == NB_ && p.nfrag == 4 && p.nwaves == NW_) return launchOne<PREC, kConv, NB_, 4, NW_>(a, gx, stream);
-    NSG_CASE(2, 4) NSG_CASE(2, 3) NSG_CASE(2, 2) NSG_CASE(2, 1)
-    NSG_CASE(1, 4) NSG_CASE(1, 3) NSG_CASE(1, 2) NSG_CASE(1, 1)
+#define NSG_CASE(NB_, NF_, NW_) \
+    if (p.nb == NB_ && p.nfrag == NF_ && p.nwaves == NW_) return launchOne<PREC, kConv, NB_, NF_, NW_>(a, gx, stream);
+    NSG_CASE(2, 4, 4) NSG_CASE(2, 4, 3) NSG_CASE(2, 4, 2) NSG_CASE(2, 4, 1)
+    NSG_CASE(1, 4, 4) NSG_CASE(1, 4, 3) NSG_CASE(1, 4, 2) NSG_CASE(1, 4, 1)
+    // small-batch tiles: fewer channels per wave, four waves share one input image
+    NSG_CASE(2, 2, 4) NSG_CASE(2, 1, 4) NSG_CASE(1, 2, 4) NSG_CASE(1, 1, 4)
 #undef NSG_CASE
     return hipErrorInvalidValue;
 }

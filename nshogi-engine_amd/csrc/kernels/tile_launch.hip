@@ -9,19 +9,40 @@ namespace nsg {
 
 ConvPlan chooseConvPlan(int batch, int cout, int computeUnits) {
     ConvPlan p;
+    const int groups = cout / (kNfrag * 16); // 64-channel weight groups
+    // Full tiles: 4 fragments (64 channels) per wave, widest workgroup that divides
+    // the channel groups (its waves share one LDS image of the input tile).
     p.nfrag = kNfrag;
-    const int groups = cout / (kNfrag * 16); // 64-channel wave groups
-    // Widest workgroup that divides the channel groups: all its waves share
-    // one LDS image of the input tile.
     p.nwaves = (groups % 4 == 0) ? 4 : (groups % 3 == 0) ? 3 : (groups % 2 == 0) ? 2 : 1;
-    // Two boards per workgroup waste less of the last 16-row fragment
-    // (162 -> 176 rows vs 81 -> 96) but halve the grid: use them once the
-    // grid still covers most of the chip.
-    const int wgs2 = ((batch + 1) / 2) * (groups / p.nwaves);
-    p.nb = (wgs2 * 4 >= computeUnits * 3) ? 2 : 1;
-    if (const char* e = getenv("NSG_CONV_NB")) { // tuning knob
+    // Two boards per workgroup waste less of the last 16-row fragment (162 -> 176
+    // rows vs 81 -> 96) but halve the grid: use them once the grid still covers
+    // most of the chip.
+    const int simds = computeUnits * 4;
+    auto waves = [&](int nb, int nfrag) { return ((batch + nb - 1) / nb) * (cout / (16 * nfrag)); };
+    p.nb = (waves(2, 4) * 4 >= simds * 3) ? 2 : 1;
+    // Small batches: a wave's run time is set by fragments-per-wave x K, so when
+    // the grid leaves SIMDs idle give each wave fewer channels (2 or 1 fragments,
+    // four waves per workgroup) until the chip is covered.
+    if (waves(p.nb, 4) * 4 < simds * 3) {
+        for (int nf : {2, 1}) {
+            for (int nb : {2, 1}) {
+                if (cout % (4 * nf * 16) != 0) continue;
+                if (waves(nb, nf) * 4 >= simds * 3 || (nf == 1 && nb == 1)) {
+                    p.nb = nb; p.nfrag = nf; p.nwaves = 4;
+                    goto chosen;
+                }
+            }
+        }
+    }
+chosen:
+    if (const char* e = getenv("NSG_CONV_NB")) { // tuning knobs
         const int v = atoi(e);
         if (v == 1 || v == 2) p.nb = v;
+    }
+    if (const char* e = getenv("NSG_CONV_NFRAG")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2) { p.nfrag = v; p.nwaves = 4; }
+        if (v == 4) { p.nfrag = 4; p.nwaves = (groups % 4 == 0) ? 4 : (groups % 3 == 0) ? 3 : (groups % 2 == 0) ? 2 : 1; }
     }
     return p;
 }
@@ -75,7 +96,7 @@ void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfra
 }
 
 bool canRunTrunk(int cout, const ConvPlan& plan) {
-    return plan.nfrag == 4 && cout == plan.nwaves * 64 && (plan.nwaves == 4 || plan.nwaves == 3);
+    return plan.nfrag == kNfrag && cout == plan.nwaves * 64 && (plan.nwaves == 4 || plan.nwaves == 3);
 }
 
 hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,

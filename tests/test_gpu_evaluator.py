@@ -61,6 +61,17 @@ def test_config2_net_10x192_batch64(nsg, oracle):
     check((p[idx], v[idx], d[idx]), (po, vo, do), TOL)
 
 
+@pytest.mark.parametrize("channels,batch", [(192, 256), (256, 130), (256, 300), (128, 512), (384, 96)])
+def test_tile_plans_across_batch_sizes(nsg, oracle, channels, batch):
+    """Every tile plan the heuristic can pick (1/2 boards per workgroup, 1/2/4
+    fragments per wave) gives the same answers: sample boards vs the oracle."""
+    ev, blob = make(nsg, 1, channels, batch, seed=channels + batch)
+    bb = nsg.synth.random_batch(batch, 86, seed=batch)
+    p, v, d = ev.compute_blocking(bb)
+    idx = [0, 1, batch // 2, batch - 2, batch - 1]
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), 2e-4)
+
+
 def test_outputs_in_range_and_finite(nsg):
     ev, _ = make(nsg, 2, 64, 32, seed=9)
     p, v, d = ev.compute_blocking(nsg.synth.random_batch(32, 86, seed=1))
