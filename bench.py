@@ -201,7 +201,7 @@ def main():
             "forward_ms_hip_events": prof["forward_ms_total"] / max(prof["forwards"], 1),
             "device": info["device_name"], "compute_units": info["compute_units"],
         }
-        if not args.no_host_path:
+        if not args.no_host_path and world == 1:
             # the reference's own definition: computeBlocking incl. H2D/D2H (batchsize.cc:61-79)
             pol = np.empty((B, 2187), np.float32)
             win = np.empty(B, np.float32)

@@ -47,6 +47,8 @@
 
 #include "kernels.h"
 
+#include <atomic>
+
 namespace nsg {
 namespace tile {
 
@@ -661,13 +663,25 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
     hipError_t err;
     if (MODE == kConv && a.res) {
         auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, (MODE == kConv)>;
-        err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
-        if (err != hipSuccess) return err;
+        static std::atomic<int> attrDevMask{0}; // per kernel instantiation: devices whose attribute is set
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!(attrDevMask.load() & (1 << dev))) {
+            err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
+            if (err != hipSuccess) return err;
+            attrDevMask.fetch_or(1 << dev);
+        }
         hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a);
     } else {
         auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false>;
-        err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
-        if (err != hipSuccess) return err;
+        static std::atomic<int> attrDevMask{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!(attrDevMask.load() & (1 << dev))) {
+            err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
+            if (err != hipSuccess) return err;
+            attrDevMask.fetch_or(1 << dev);
+        }
         hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a);
     }
     return hipGetLastError();
