@@ -180,8 +180,11 @@ struct Args {
 
 // Single-board conv tiles are small enough for two workgroups per CU (two waves
 // per SIMD): the second argument caps registers at 256 so both fit.
-template <int MODE, int SIZE, int NWAVES>
-constexpr int minWavesPerSimd() { return (MODE == kConv && SIZE == 1 && NWAVES >= 3) ? 2 : 1; }
+template <int MODE, int SIZE, int NWAVES, int NFRAG = 4>
+constexpr int minWavesPerSimd() {
+    // (two boards with 2 fragments per wave would spill at 256 registers: measured slower)
+    return (MODE == kConv && SIZE == 1 && (NWAVES >= 3 || NFRAG <= 2)) ? 2 : 1;
+}
 
 // One layer's work for this workgroup.  RES: 0 = no residual, 1 = residual,
 // 2 = decided at run time by A.res (persistent trunk kernel).
@@ -631,7 +634,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 }
 
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES>
-__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES>())) void tileKernel(const Args A) {
+__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG>())) void tileKernel(const Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0>(A, smem, true);
 }
