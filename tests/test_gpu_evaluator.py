@@ -99,6 +99,42 @@ def test_batch_composition_independence_full_size(nsg):
     assert (pr == pr[0]).all() and (vr == vr[0]).all() and (dr == dr[0]).all()
 
 
+def test_f16x3_full_size_properties(nsg, oracle):
+    """The default precision at BASELINE's full size (20x256, B=512): a sample of
+    boards against the oracle at the north_star tolerance, and bit-exact
+    independence from batch composition and slot."""
+    ev, blob = make(nsg, 20, 256, 512, precision="f16x3", seed=4, bn="identity")
+    bb = nsg.synth.random_batch(512, 86, seed=8)
+    p, v, d = ev.compute_blocking(bb)
+    idx = [0, 255, 511]
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), 1e-4)  # 10x tighter than 1e-3
+    perm = np.random.default_rng(1).permutation(512)
+    p2, v2, d2 = ev.compute_blocking(bb[perm])
+    np.testing.assert_array_equal(p2, p[perm])
+    np.testing.assert_array_equal(v2, v[perm])
+    np.testing.assert_array_equal(d2, d[perm])
+    assert ((v >= 0) & (v <= 1)).all() and ((d >= 0) & (d <= 1)).all() and np.isfinite(p).all()
+
+
+def test_f16x3_extreme_magnitudes(nsg, oracle):
+    """Weights spanning many binades (the per-tensor power-of-two scale must keep
+    hi/lo in f16 range) and large activations (BN gamma 8): still f32-equivalent."""
+    w = nsg.weights.make_random(2, 64, seed=21, bn="random")
+    rng = np.random.default_rng(3)
+    for k in ("b0_w1", "b1_w2"):
+        w[k] = (w[k] * np.exp2(rng.integers(-12, 3, size=w[k].shape[:1])).reshape(-1, 1, 1, 1)).astype(np.float32)
+    w["stem_bn"][0] *= 8.0
+    blob = nsg.weights.to_blob(w)
+    ev = nsg.Evaluator(0, 8, 86, precision="f16x3")
+    ev.load_memory(blob)
+    bb = nsg.synth.random_batch(8, 86, seed=2)
+    out = ev.compute_blocking(bb)
+    ref = oracle.net(blob).evaluate(bb)
+    scale = max(1.0, float(np.abs(ref[0]).max()))
+    assert float(np.abs(out[0] - ref[0]).max()) <= 2e-5 * scale
+    assert float(np.abs(out[1] - ref[1]).max()) <= 1e-5 and float(np.abs(out[2] - ref[2]).max()) <= 1e-5
+
+
 def test_nonblocking_await_contract(nsg, oracle):
     """computeNonBlocking -> await; results defined only after await (trt.cc:234-283)."""
     ev, blob = make(nsg, 2, 64, 64, seed=6)

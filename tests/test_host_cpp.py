@@ -44,7 +44,7 @@ def test_cpu_executors_through_cpp_adapter(nsg, oracle, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [(0, 2e-4)])
+@pytest.mark.parametrize("precision,tol", [(0, 2e-4), (3, 2e-4)])
 def test_hip_through_cpp_adapter(nsg, oracle, tmp_path, precision, tol):
     w = nsg.weights.make_random(2, 64, seed=11, bn="random")
     blob = nsg.weights.to_blob(w)
