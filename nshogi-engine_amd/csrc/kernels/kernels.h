@@ -92,7 +92,7 @@ hipError_t launchValueOut(const float* h, const float* w2, const float* b2,
                           float* value, float* draw, int batch, int hidden,
                           hipStream_t stream);
 
-// Fragment-ordered weights: number of 16-byte lane records INCLUDING the two
+// Fragment-ordered weights: number of 16-byte lane records INCLUDING the eight
 // trailing zero slabs the kernel's prefetch may touch.
 size_t tileWeightRecords(int taps, int kdim, int cout, int prec);
 // Host-side re-layout.  get(n, k, tap) returns the (already BN-folded) weight

@@ -261,8 +261,8 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     }
 
     // weight stream: slab q = (kc*taps + tap)*2 + s, NFRAG 1-KiB records per wave,
-    // held in a register ring kRing slabs deep (slab q+2 is requested while slab q
-    // computes, so a weight load has a whole slab of MFMAs to cover its L2 latency).
+    // held in a register ring kRing slabs deep (slab q+kRing-1 is requested while slab
+    // q computes, so a weight load has whole slabs of MFMAs to cover its L2 latency).
     constexpr int kSlabsPerTap = kSplit ? 3 : 2;
     constexpr int kSlabs = kSlabsPerTap * G::kTaps;    // slabs per channel chunk
     // LDS byte offset of slab s's row fragments inside the chunk image: tap shift +
@@ -274,17 +274,22 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         const int piece = kSplit ? (r == 2 ? 4 : 0) : r * 4;
         return (G::kBoards ? ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16 : 0) + piece * G::kPlane;
     };
-    constexpr int kRing = (kSlabs % 3 == 0) ? 3 : 2;
+    // Ring depths: a slab of a full tile is 44 MFMAs (~700 cycles) and covers an L2
+    // round trip with one slab of lead; a small-batch tile has as few as 6 MFMAs per
+    // slab, so its weight ring runs 8 slabs ahead and its row fragments 2 slabs ahead.
+    constexpr bool kDeep = (NFRAG <= 2) && (kSlabs % 9 == 0);
+    constexpr int kRing = kDeep ? 9 : ((kSlabs % 3 == 0) ? 3 : 2);   // weight records
+    constexpr int kRingA = (kDeep || (NFRAG <= 2 && kSlabs % 3 == 0)) ? 3 : 2; // row fragments
     constexpr int kMfmaPerPair = (PREC == kFp32) ? 4 : 1;
     const size_t slabStride = (size_t)nft * 64;
     const u32x4* wp = A.w + (size_t)waveGroup * NFRAG * 64 + lane;
     u32x4 w[kRing][NFRAG];
+    constexpr int kLead = (kRing == 2) ? 2 : kRing - 1; // slabs requested ahead of use
 #pragma unroll
-    for (int j = 0; j < NFRAG; ++j) {
-        w[0][j] = wp[j * 64];
-        w[1][j] = wp[slabStride + j * 64];
-    }
-    wp += 2 * slabStride; // -> slab 2
+    for (int q = 0; q < kLead; ++q)
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) w[q % kRing][j] = wp[(size_t)q * slabStride + j * 64];
+    wp += (size_t)kLead * slabStride;
 
     f32x4 acc[G::kMF][NFRAG];
 #pragma unroll
@@ -298,39 +303,41 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     __syncthreads();
 
     NSG_STAMP(1);
-    u32x4 a[2][G::kMF]; // row fragments: current slab / next slab
+    u32x4 a[kRingA][G::kMF]; // row fragments: current slab + the next kRingA-1
     for (int kc = 0; kc < nkc; ++kc) {
         const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
 #pragma unroll
-        for (int f = 0; f < G::kMF; ++f) // slab 0 of this chunk (just published by the barrier)
-            a[0][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + slabOff(0));
+        for (int q = 0; q < kRingA - 1; ++q) // first slabs of this chunk (just published by the barrier)
+#pragma unroll
+            for (int f = 0; f < G::kMF; ++f)
+                if (q < kSlabs) a[q][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + slabOff(q));
         // next chunk's tile: global -> registers now, registers -> LDS after the last slab
         // (the last iteration re-loads its own chunk: harmless, keeps st[] in registers)
         NSG_STAGE_LOAD(kc + 1 < nkc ? kc + 1 : kc)
 #pragma unroll
         for (int s = 0; s < kSlabs; ++s) {
             // -- requests for later slabs
-            if (s + 1 < kSlabs) {
-                const int off1 = slabOff(s + 1);
+            if (s + kRingA - 1 < kSlabs) {
+                const int off1 = slabOff(s + kRingA - 1);
 #pragma unroll
                 for (int f = 0; f < G::kMF; ++f)
-                    a[(s + 1) & 1][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + off1);
+                    a[(s + kRingA - 1) % kRingA][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + off1);
             }
-            if constexpr (kRing == 3) {
+            if constexpr (kRing >= 3) {
 #pragma unroll
-                for (int j = 0; j < NFRAG; ++j) w[(s + 2) % 3][j] = wp[j * 64];
+                for (int j = 0; j < NFRAG; ++j) w[(s + kRing - 1) % kRing][j] = wp[j * 64];
             }
             // -- this slab's MFMAs
 #pragma unroll
             for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w[s % kRing][j], a[s & 1][f]);
+                for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w[s % kRing][j], a[s % kRingA][f]);
             if constexpr (kRing == 2) {
 #pragma unroll
                 for (int j = 0; j < NFRAG; ++j) w[s % 2][j] = wp[j * 64];
             }
             wp += slabStride;
-            if constexpr (kRing == 3) {
+            if constexpr (kRing >= 3) {
                 // interleave: one LDS read (+ one weight load) per NFRAG row-fragment MFMAs
 #pragma unroll
                 for (int f = 0; f < G::kMF; ++f) {

@@ -212,8 +212,8 @@ hipError_t launchValueOut(const float* h, const float* w2, const float* b2,
 //   f32  : 4 values, input channel kc*32 + s*16 + 4*g + i          (i = 0..3)
 //   16b  : 8 values, input channel kc*64 + s*32 + 8*g + i          (i = 0..7)
 //   f16x3: 8 values, input channel kc*32 + 8*g + i; s = 0: hi, 1: lo, 2: hi
-// Two zero slabs are appended so the kernel's two-slab-ahead prefetch never
-// reads past the allocation.
+// Eight zero slabs are appended so the kernel's prefetch (up to 8 slabs ahead for
+// small-batch tiles) never reads past the allocation.
 // ---------------------------------------------------------------------------
 static inline uint16_t hostF32ToF16(float f) {
     const _Float16 h = (_Float16)f;
@@ -231,7 +231,7 @@ static inline uint16_t hostF32ToBf16(float f) {
 
 size_t tileWeightRecords(int taps, int kdim, int cout, int prec) {
     const int nkc = kdim / chunkChannels(prec);
-    return ((size_t)nkc * taps * slabsPerTap(prec) + 2) * (cout / 16) * 64;
+    return ((size_t)nkc * taps * slabsPerTap(prec) + 8) * (cout / 16) * 64; // + 8 zero slabs: deepest prefetch
 }
 
 void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
