@@ -79,6 +79,24 @@ __global__ __launch_bounds__(kThreads) void extractNHWC(
     __syncthreads();
     const int n = 81 * channels;
     uint32_t* out = dst + (size_t)b * n;
+    if ((channels & 1) == 0) {
+        // even C: a position's 81*C dwords start 8-byte aligned -> 8-byte stores
+        const int half = channels >> 1;
+        for (int j = threadIdx.x; j < 81 * half; j += kThreads) {
+            const int sq = j / half;
+            const int c = (j - sq * half) * 2;
+            uint32_t v[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint4 bb = sBoard[c + i];
+                const uint64_t lo = ((uint64_t)bb.y << 32) | bb.x;
+                const uint64_t hi = ((uint64_t)bb.w << 32) | bb.z;
+                v[i] = selectBit(lo, hi, sq);
+            }
+            *reinterpret_cast<uint2*>(out + (size_t)sq * channels + c) = make_uint2(v[0], v[1]);
+        }
+        return;
+    }
     for (int j = threadIdx.x; j < n; j += kThreads) {
         const int sq = j / channels;
         const int c = j - sq * channels;
