@@ -1,0 +1,423 @@
+// selfplay.cc -- see selfplay.h.
+#include "selfplay.h"
+
+#include <nshogi_engine_amd/evaluate/evaluator.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace nshogi {
+namespace engine {
+namespace selfplay {
+
+using shogi::Color;
+using shogi::FeaturePlane;
+using shogi::Move;
+using shogi::MoveList;
+
+namespace {
+
+void freeTree(Node* N) {
+    if (!N) return;
+    for (uint16_t I = 0; I < N->NumChildren; ++I) freeTree(N->Edges[I].Child);
+    delete[] N->Edges;
+    delete N;
+}
+
+inline uint64_t mix64(uint64_t X) {
+    X ^= X >> 33; X *= 0xff51afd7ed558ccdULL; X ^= X >> 33; X *= 0xc4ceb9fe1a85ec53ULL; X ^= X >> 33;
+    return X;
+}
+
+constexpr int kCacheMoves = 112; // positions with more legal moves are not cached
+
+} // namespace
+
+// Evaluation cache: hash -> legal-move logits + values (mcts::EvalCache's role,
+// selfplay/worker.cc:367-378, frame.cc:108-111).  Direct mapped, per engine.
+struct Engine::Cache {
+    struct Entry {
+        uint64_t Hash = 0;
+        uint16_t N = 0;
+        float Win = 0, Draw = 0;
+        float Logit[kCacheMoves];
+    };
+    std::vector<Entry> Entries;
+    explicit Cache(std::size_t Count) : Entries(Count) {}
+    const Entry* load(uint64_t Hash, uint16_t N) const {
+        const Entry& E = Entries[Hash % Entries.size()];
+        return (E.Hash == Hash && E.N == N) ? &E : nullptr;
+    }
+    void store(uint64_t Hash, uint16_t N, const float* Logit, float Win, float Draw) {
+        if (N > kCacheMoves) return;
+        Entry& E = Entries[Hash % Entries.size()];
+        E.Hash = Hash; E.N = N; E.Win = Win; E.Draw = Draw;
+        std::memcpy(E.Logit, Logit, N * sizeof(float));
+    }
+};
+
+class Game {
+ public:
+    Game(Engine* E, uint64_t Stream) : Eng(E), StreamId(Stream) { newGame(); }
+    ~Game() { freeTree(Root); }
+    Game(const Game&) = delete;
+    Game& operator=(const Game&) = delete;
+
+    // Advances the state machine until a leaf needs the network; writes its feature
+    // planes to `Slot` and returns true.  Returns false if the budget of host-only
+    // playouts for this call is used up (everything was terminal or cached).
+    bool advanceUntilEvaluation(FeaturePlane* Slot) {
+        for (int Guard = 0; Guard < 20000; ++Guard) {
+            switch (Ph) {
+            case Phase::RootPreparation: prepareRoot(); break;
+            case Phase::LeafSelection: selectLeaf(); break;
+            case Phase::LeafTerminalChecking:
+                if (checkTerminal()) {
+                    shogi::buildFeatures(S, Config, Slot);
+                    Ph = Phase::Evaluation;
+                    return true;
+                }
+                break;
+            case Phase::Evaluation: return false; // still waiting (should not happen)
+            case Phase::Backpropagation: backpropagate(); break;
+            case Phase::Transition: transition(); break;
+            case Phase::Judging: judge(); break;
+            }
+        }
+        return false;
+    }
+
+    // Frame::setEvaluation<false> (frame.cc:93-136) for the pending leaf.
+    void setEvaluation(const float* Policy, float Win, float Draw) {
+        const uint16_t N = Leaf->NumChildren;
+        const Color Us = S.sideToMove();
+        for (uint16_t I = 0; I < N; ++I) {
+            Move M;
+            M.V = Leaf->Edges[I].Move16;
+            Logits[I] = Policy[shogi::moveIndex(Us, M)];
+        }
+        if (Eng->EvalCache) Eng->EvalCache->store(S.hash(), N, Logits, Win, Draw);
+        finishEvaluation(N, Win, Draw);
+    }
+
+ private:
+    enum class Phase { RootPreparation, LeafSelection, LeafTerminalChecking, Evaluation, Backpropagation, Transition, Judging };
+
+    void newGame() {
+        freeTree(Root);
+        Root = nullptr;
+        S = shogi::State();
+        Rng.seed(mix64(Eng->Opt.Seed ^ mix64(StreamId * 0x9e3779b97f4a7c15ULL + Serial)));
+        ++Serial;
+        // worker.cc:132-150
+        std::uniform_int_distribution<int> MaxPly(Eng->Opt.MaxPlyMin, Eng->Opt.MaxPlyMax);
+        Config.MaxPly = (uint16_t)MaxPly(Rng);
+        Config.BlackDrawValue = Config.WhiteDrawValue = 0.5f;
+        if (Eng->Opt.RandomDrawValue && (Rng() % 4) >= 2) {
+            Config.BlackDrawValue = std::uniform_real_distribution<float>(0.f, 1.f)(Rng);
+            Config.WhiteDrawValue = 1.0f - Config.BlackDrawValue;
+        }
+        GameMoves = 0;
+        Ph = Phase::RootPreparation;
+    }
+
+    float drawValue(Color C) const { return C == shogi::Black ? Config.BlackDrawValue : Config.WhiteDrawValue; }
+
+    void prepareRoot() { // worker.cc:159-215
+        freeTree(Root);
+        Root = new Node();
+        RootPly = S.ply();
+        MoveList L;
+        S.generateLegalMoves(L);
+        const double R = std::uniform_real_distribution<double>(0.0, 1.0)(Rng);
+        if (L.size() == 1 || R > Eng->Opt.FullSearchRatio) {
+            Budget = L.size() == 1 ? 1u : (uint32_t)std::max(1, Eng->Opt.NumPlayouts / 4);
+            FullSearch = false;
+        } else {
+            Budget = (uint32_t)Eng->Opt.NumPlayouts;
+            FullSearch = true;
+        }
+        Ph = Phase::LeafSelection;
+    }
+
+    void undoToRoot() {
+        while (S.ply() > RootPly) S.undoMove();
+    }
+
+    // worker.cc:726-770
+    double winRateOfChild(Color SideToMove, const Node* Child) const {
+        const double V = (double)Child->Visits;
+        const double WinRate = (V - Child->WinSum) / V;
+        const double DrawRate = Child->DrawSum / V;
+        return DrawRate * (double)drawValue(SideToMove) + (1.0 - DrawRate) * WinRate;
+    }
+
+    Edge* pickEdge(Node* N) const { // PUCT, worker.cc:688-715
+        const double C = 1.25 * std::sqrt((double)N->Visits);
+        const Color Us = S.sideToMove();
+        double Best = std::numeric_limits<double>::lowest();
+        Edge* BestEdge = nullptr;
+        for (uint16_t I = 0; I < N->NumChildren; ++I) {
+            Edge* E = &N->Edges[I];
+            const Node* Ch = E->Child;
+            const double Score = (Ch == nullptr || Ch->Visits == 0)
+                                     ? C * (double)E->Prior
+                                     : C * (double)E->Prior / (double)(1 + Ch->Visits) + winRateOfChild(Us, Ch);
+            if (Score > Best) {
+                Best = Score;
+                BestEdge = E;
+            }
+        }
+        return BestEdge;
+    }
+
+    void selectLeaf() { // worker.cc:217-266
+        undoToRoot();
+        Node* N = Root;
+        for (;;) {
+            if (N->Visits == 0 || N->NumChildren == 0 || N->Repetition != 0) break;
+            if (S.ply() >= Config.MaxPly) break;
+            Edge* E = pickEdge(N);
+            S.doMove(S.moveFrom16(E->Move16));
+            if (!E->Child) {
+                E->Child = new Node();
+                E->Child->Parent = N;
+            }
+            N = E->Child;
+        }
+        Leaf = N;
+        Ph = Phase::LeafTerminalChecking;
+    }
+
+    void setTerminal(float Win, float Draw) { // setEvaluation<true>(nullptr, ...)
+        Leaf->WinPred = Win;
+        Leaf->DrawPred = Draw;
+        Ph = Phase::Backpropagation;
+    }
+
+    // returns true when the leaf needs a network evaluation; worker.cc:268-381
+    bool checkTerminal() {
+        if (Leaf->Visits > 0) {
+            Ph = Phase::Backpropagation;
+            return false;
+        }
+        const shogi::RepetitionStatus RS = S.repetitionStatus(true);
+        if (RS != shogi::NoRepetition) {
+            Leaf->Repetition = (uint8_t)RS;
+            if (RS == shogi::WinRepetition) setTerminal(1.0f, 0.0f);
+            else if (RS == shogi::LossRepetition) setTerminal(0.0f, 0.0f);
+            else setTerminal(drawValue(S.sideToMove()), 1.0f);
+            return false;
+        }
+        if (Config.Declare27 && Leaf != Root && S.canDeclare()) {
+            setTerminal(1.0f, 0.0f);
+            return false;
+        }
+        MoveList L;
+        S.generateLegalMoves(L);
+        if (L.size() == 0) {
+            setTerminal(0.0f, 0.0f);
+            return false;
+        }
+        if (S.ply() >= Config.MaxPly) {
+            setTerminal(drawValue(S.sideToMove()), 1.0f);
+            return false;
+        }
+        // expand (Node::expand)
+        Leaf->NumChildren = (uint16_t)L.size();
+        Leaf->Edges = new Edge[L.size()];
+        for (int I = 0; I < L.size(); ++I) Leaf->Edges[I] = Edge{L[I].move16(), 0.0f, nullptr};
+        if (Eng->EvalCache) {
+            if (const auto* E = Eng->EvalCache->load(S.hash(), Leaf->NumChildren)) {
+                std::memcpy(Logits, E->Logit, Leaf->NumChildren * sizeof(float));
+                ++Eng->St.CacheHits;
+                finishEvaluation(Leaf->NumChildren, E->Win, E->Draw);
+                return false;
+            }
+        }
+        return true;
+    }
+
+    // softmax over the legal-move logits, Dirichlet noise at a full-search root
+    // (frame.cc:113-135), priors into the edges
+    void finishEvaluation(uint16_t N, float Win, float Draw) {
+        float Max = -std::numeric_limits<float>::infinity();
+        for (uint16_t I = 0; I < N; ++I) Max = std::max(Max, Logits[I]);
+        float Sum = 0.f;
+        for (uint16_t I = 0; I < N; ++I) {
+            Logits[I] = std::exp(Logits[I] - Max);
+            Sum += Logits[I];
+        }
+        for (uint16_t I = 0; I < N; ++I) Logits[I] /= Sum;
+        if (Leaf == Root && FullSearch) {
+            std::gamma_distribution<double> Gamma(0.15, 1.0); // worker.cc:650-652
+            double NoiseSum = 0.0;
+            for (uint16_t I = 0; I < N; ++I) {
+                Noise[I] = Gamma(Rng);
+                NoiseSum += Noise[I];
+            }
+            if (NoiseSum <= 0.0) NoiseSum = 1.0;
+            constexpr double Eps = 0.25;
+            for (uint16_t I = 0; I < N; ++I)
+                Logits[I] = (float)((1 - Eps) * (double)Logits[I] + Eps * Noise[I] / NoiseSum);
+        }
+        for (uint16_t I = 0; I < N; ++I) Leaf->Edges[I].Prior = Logits[I];
+        Leaf->WinPred = Win;
+        Leaf->DrawPred = Draw;
+        Ph = Phase::Backpropagation;
+    }
+
+    void backpropagate() { // node.h:170-202, worker.cc:383-426
+        const float Win = Leaf->WinPred, Draw = Leaf->DrawPred;
+        bool Flip = false;
+        for (Node* N = Leaf; N != nullptr; N = N->Parent, Flip = !Flip) {
+            N->WinSum += Flip ? 1.0 - (double)Win : (double)Win;
+            N->DrawSum += (double)Draw;
+            ++N->Visits;
+        }
+        undoToRoot();
+        ++Eng->St.Playouts;
+        if (Root->NumChildren == 1 || Root->Visits >= Budget) Ph = Phase::Transition;
+        else Ph = Phase::LeafSelection;
+    }
+
+    void transition() { // most visited move, ties by prior (worker.cc:562-596)
+        undoToRoot();
+        uint32_t MaxVisits = 0;
+        Edge* Best = nullptr;
+        for (uint16_t I = 0; I < Root->NumChildren; ++I) {
+            Edge* E = &Root->Edges[I];
+            const Node* Ch = E->Child;
+            if (Ch == nullptr || Ch->Visits == 0) {
+                if (Best == nullptr) Best = E;
+                else if ((Best->Child == nullptr || Best->Child->Visits == 0) && E->Prior > Best->Prior) Best = E;
+                continue;
+            }
+            if (Ch->Visits > MaxVisits) {
+                MaxVisits = Ch->Visits;
+                Best = E;
+            } else if (Ch->Visits == MaxVisits && E->Prior > Best->Prior) {
+                Best = E;
+            }
+        }
+        const Move M = S.moveFrom16(Best->Move16);
+        S.doMove(M);
+        ++GameMoves;
+        ++Eng->St.Moves;
+        Eng->Digest += mix64(((uint64_t)StreamId << 40) ^ ((uint64_t)(Serial - 1) << 20) ^ ((uint64_t)GameMoves << 32) ^ M.V);
+        Ph = Phase::Judging;
+    }
+
+    void finish(Color Winner) {
+        if (Winner == shogi::Black) ++Eng->St.GamesBlack;
+        else if (Winner == shogi::White) ++Eng->St.GamesWhite;
+        else ++Eng->St.GamesDraw;
+        Eng->St.MovesOfFinishedGames += GameMoves;
+        newGame();
+    }
+
+    void judge() { // worker.cc:477-526 (without the df-pn call)
+        const shogi::RepetitionStatus RS = S.repetitionStatus(true);
+        if (RS == shogi::WinRepetition) return finish(S.sideToMove());
+        if (RS == shogi::LossRepetition) return finish(~S.sideToMove());
+        if (RS == shogi::Repetition) return finish(shogi::NoColor);
+        if (Config.Declare27 && S.canDeclare()) return finish(S.sideToMove());
+        MoveList L;
+        S.generateLegalMoves(L);
+        if (L.size() == 0) return finish(~S.sideToMove());
+        if (S.ply() >= Config.MaxPly) return finish(shogi::NoColor);
+        Ph = Phase::RootPreparation;
+    }
+
+    Engine* Eng;
+    uint64_t StreamId;
+    uint64_t Serial = 0;
+    shogi::State S;
+    shogi::StateConfig Config;
+    std::mt19937_64 Rng;
+    Node* Root = nullptr;
+    Node* Leaf = nullptr;
+    int RootPly = 0;
+    uint32_t Budget = 1;
+    bool FullSearch = false;
+    uint32_t GameMoves = 0;
+    Phase Ph = Phase::RootPreparation;
+    float Logits[600];
+    double Noise[600];
+};
+
+struct Engine::Group {
+    std::vector<std::unique_ptr<Game>> Games;
+    std::unique_ptr<evaluate::Evaluator> Ev;
+    std::vector<int> Pending;
+    std::size_t Count = 0;
+    bool InFlight = false;
+};
+
+Engine::Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& O, uint64_t EngineIndex, bool PinMemory)
+    : Opt(O) {
+    if (Opt.EvalCacheEntries) EvalCache = std::make_unique<Cache>(Opt.EvalCacheEntries);
+    infer::Infer* Exec[2] = {Exec0, Exec1};
+    for (int G = 0; G < 2; ++G) {
+        Groups[G] = std::make_unique<Group>();
+        Groups[G]->Ev = std::make_unique<evaluate::Evaluator>(EngineIndex * 2 + G, shogi::NumFeaturePlanes,
+                                                              (std::size_t)Opt.GamesPerGroup, Exec[G], PinMemory);
+        Groups[G]->Pending.resize(Opt.GamesPerGroup);
+        for (int I = 0; I < Opt.GamesPerGroup; ++I)
+            Groups[G]->Games.push_back(std::make_unique<Game>(
+                this, (EngineIndex * 2 + (uint64_t)G) * 1000003ULL + (uint64_t)I));
+    }
+}
+
+Engine::~Engine() {
+    drain();
+}
+
+void Engine::apply(Group& G) {
+    if (!G.InFlight) return;
+    G.Ev->await();
+    for (std::size_t K = 0; K < G.Count; ++K) {
+        G.Games[G.Pending[K]]->setEvaluation(G.Ev->getPolicy() + K * shogi::MoveIndexMax,
+                                             G.Ev->getWinRate()[K], G.Ev->getDrawRate()[K]);
+    }
+    G.InFlight = false;
+}
+
+void Engine::collect(Group& G) {
+    std::size_t N = 0;
+    static_assert(sizeof(FeaturePlane) == sizeof(ml::FeatureBitboard), "feature plane layout");
+    auto* Slots = reinterpret_cast<FeaturePlane*>(G.Ev->getFeatureBitboards());
+    for (std::size_t I = 0; I < G.Games.size(); ++I) {
+        if (G.Games[I]->advanceUntilEvaluation(Slots + N * shogi::NumFeaturePlanes)) {
+            G.Pending[N++] = (int)I;
+        }
+    }
+    G.Count = N;
+    if (N == 0) return;
+    G.Ev->computeNonBlocking(N);
+    G.InFlight = true;
+    ++St.Batches;
+    St.Evaluations += N;
+}
+
+void Engine::step() {
+    for (int G = 0; G < 2; ++G) {
+        apply(*Groups[G]);   // results of this group's previous batch
+        collect(*Groups[G]); // host search of this group while the other group's batch computes
+    }
+}
+
+void Engine::drain() {
+    for (int G = 0; G < 2; ++G) apply(*Groups[G]);
+}
+
+void Engine::run(const volatile bool* Stop, uint64_t MaxFinishedGames) {
+    while (!*Stop && (MaxFinishedGames == 0 || St.finished() < MaxFinishedGames)) step();
+    drain();
+}
+
+} // namespace selfplay
+} // namespace engine
+} // namespace nshogi

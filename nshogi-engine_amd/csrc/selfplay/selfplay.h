@@ -1,0 +1,115 @@
+// selfplay.h -- self-play rollout engine on top of the batched evaluator
+// (BASELINE metric #2 "self-play games/sec").
+//
+// Follows the reference's AlphaZero-mode frame state machine
+// (/root/reference/src/selfplay/worker.cc:55-110 dispatch; prepareRoot :159-215,
+// selectLeaf :217-266, checkTerminal :268-381, backpropagate :383-410,
+// sequentialHalving (non-Gumbel part) :412-426, transition :528-610, judge
+// :477-526; Frame::setEvaluation frame.cc:93-136; PUCT worker.cc:688-715;
+// win-rate blending :726-770) with these deliberate differences:
+//   * one thread owns its games and steps them in two groups: while one group's
+//     leaf batch is on the GPU the thread searches the other group (the reference
+//     brackets a blocking GPU call with serial host loops,
+//     selfplay/evaluationworker.cc:69-117);
+//   * every game has its own RNG seeded from (base seed, game serial) and batch
+//     results are slot-independent, so a run is reproducible bit for bit
+//     (the reference seeds from std::random_device, worker.cc:49-50);
+//   * the mate-in-3 dfs / df-pn solver calls (worker.cc:349-358,516-524) are not
+//     implemented: positions are searched instead;
+//   * the teacher record writer (saveworker.cc:160-182, libnshogi's SimpleTeacher
+//     format) is out of scope; finished games are only counted.
+// Rules, feature planes and the policy move index come from csrc/shogi (this
+// build's own; parity with libnshogi unpinned).
+#ifndef NSG_SELFPLAY_H
+#define NSG_SELFPLAY_H
+
+#include "../shogi/features.h"
+#include "../shogi/shogi.h"
+
+#include <nshogi_engine_amd/infer/infer.h>
+
+#include <cstdint>
+#include <memory>
+#include <random>
+#include <vector>
+
+namespace nshogi {
+namespace engine {
+namespace selfplay {
+
+struct Options {
+    int GamesPerGroup = 256;     // concurrent games per group (2 groups per engine)
+    int NumPlayouts = 800;       // --num-playouts (selfplay/main.cc:43-45)
+    double FullSearchRatio = 0.25; // --full-search-ratio (main.cc:54-55)
+    uint64_t Seed = 0;
+    int MaxPlyMin = 160 + 64;    // worker.cc:135-136
+    int MaxPlyMax = 512 + 128;
+    bool RandomDrawValue = true; // worker.cc:142-150
+    std::size_t EvalCacheEntries = 1 << 15; // per engine; 0 disables
+};
+
+struct Stats {
+    uint64_t Evaluations = 0;   // leaves sent to the executor
+    uint64_t CacheHits = 0;
+    uint64_t Batches = 0;
+    uint64_t Playouts = 0;      // back-propagations (incl. terminal and cached leaves)
+    uint64_t Moves = 0;
+    uint64_t GamesBlack = 0, GamesWhite = 0, GamesDraw = 0;
+    uint64_t MovesOfFinishedGames = 0;
+    uint64_t finished() const { return GamesBlack + GamesWhite + GamesDraw; }
+};
+
+struct Node;
+struct Edge {
+    uint16_t Move16;
+    float Prior;
+    Node* Child;
+};
+struct Node {
+    Node* Parent = nullptr;
+    Edge* Edges = nullptr;
+    uint32_t Visits = 0;
+    uint16_t NumChildren = 0;
+    uint8_t Repetition = 0;
+    double WinSum = 0.0, DrawSum = 0.0;
+    float WinPred = 0.f, DrawPred = 0.f;
+};
+
+class Game; // one Frame
+
+// One engine = one search thread's worth of games + its two executors.
+class Engine {
+ public:
+    // Exec[0], Exec[1]: one executor per group (not owned).  BatchMax >= GamesPerGroup.
+    Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& Opt, uint64_t EngineIndex, bool PinMemory);
+    ~Engine();
+
+    // Runs until `Stop` becomes true or `MaxFinishedGames` games have finished (0 = no limit).
+    void run(const volatile bool* Stop, uint64_t MaxFinishedGames);
+    // Single-step variant for tests: advance both groups once.
+    void step();
+    void drain(); // await in-flight batches and apply them
+
+    const Stats& stats() const { return St; }
+    // order-independent digest of every move played so far (reproducibility checks)
+    uint64_t moveDigest() const { return Digest; }
+
+ private:
+    struct Group;
+    void collect(Group& G);
+    void apply(Group& G);
+
+    Options Opt;
+    Stats St;
+    uint64_t Digest = 0;
+    std::unique_ptr<Group> Groups[2];
+    struct Cache;
+    std::unique_ptr<Cache> EvalCache;
+    friend class Game;
+};
+
+} // namespace selfplay
+} // namespace engine
+} // namespace nshogi
+
+#endif

@@ -1,0 +1,94 @@
+"""The shogi rules core (csrc/shogi) and the self-play engine (csrc/selfplay).
+libnshogi (the reference's rules library) is absent, so the core is pinned by the
+game's public perft numbers, the 593-move maximum position, and a cross-check of the
+fast legal-move generator against an independently structured make/unmake generator."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SP = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "selfplay")
+
+
+def _tool(name):
+    path = os.path.join(SP, name)
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    return path
+
+
+def run(name, *args, timeout=600):
+    r = subprocess.run([_tool(name)] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_perft_startpos_known_values():
+    # public reference values for shogi perft from the initial position
+    out = run("perft", "perft", 5).split()
+    assert out == ["1", "30", "2", "900", "3", "25470", "4", "719731", "5", "19861490"]
+
+
+def test_maximum_legal_moves_position():
+    # the well-known position with the maximum of 593 legal moves (the size of MoveList and of Frame's buffers)
+    out = run("perft", "movecount", "R8/2K1S1SSk/4B4/9/9/9/9/9/1L1L1L3 b RBGSNLP3g3n17p 1").split()
+    assert out[0] == "593" and out[1] == "593"
+
+
+@pytest.mark.parametrize("sfen,count", [
+    # nifu + drop restrictions: black has a pawn in hand; files with a black pawn are excluded
+    ("4k4/9/9/9/9/9/P8/9/4K4 b P 1", None),
+    # uchifuzume: dropping a pawn in front of the cornered king would be mate -> illegal
+    ("8k/7pp/7G1/9/9/9/9/9/K8 b P 1", None),
+])
+def test_fast_equals_slow_on_rule_positions(sfen, count):
+    out = run("perft", "movecount", sfen).split()
+    assert out[0] == out[1]
+
+
+def test_uchifuzume_is_excluded():
+    # White king 1a boxed in by its own lance 2a and pawn 2b; Black's gold on 2c guards 1b.
+    # P*1b would be checkmate by a dropped pawn -> illegal; every other pawn drop on file 1 is fine.
+    sfen = "7lk/7p1/7G1/9/9/9/9/9/K8 b P 1"
+    fast, slow = run("perft", "movecount", sfen).split()[:2]
+    assert fast == slow
+    moves = run("perft", "moves", sfen).split()
+    assert "P*1b" not in moves and "P*1c" in moves and "P*5e" in moves
+    # with a flight square for the king (no lance on 2a) the same drop is legal
+    moves = run("perft", "moves", "8k/7p1/7G1/9/9/9/9/9/K8 b P 1").split()
+    assert "P*1b" in moves
+
+
+def test_generators_agree_on_random_playouts():
+    out = run("perft", "crosscheck", 300, 11)
+    assert out.startswith("ok positions")
+
+
+def test_selfplay_cpu_random_executor_reproducible():
+    """EXECUTOR=random self-play (BASELINE config 1 plumbing): finishes games and is
+    bit-reproducible under a fixed seed; a different seed plays different games."""
+    args = ["--executor", "random", "--threads", "2", "--games-per-group", "4", "--playouts", "30",
+            "--max-games", "6"]
+    a = json.loads(run("selfplay", *args, "--seed", 5))
+    b = json.loads(run("selfplay", *args, "--seed", 5))
+    c = json.loads(run("selfplay", *args, "--seed", 6))
+    assert a["games_finished"] >= 6 and a["digest"] == b["digest"] and a["moves"] == b["moves"]
+    assert c["digest"] != a["digest"]
+    assert a["black"] + a["white"] + a["draw"] == a["games_finished"]
+
+
+@pytest.mark.gpu
+def test_selfplay_hip_reproducible(nsg, tmp_path):
+    """Self-play on the HIP evaluator: move selection is bit-identical under a fixed
+    seed (north_star) -- across runs and regardless of how games are grouped into batches."""
+    path = tmp_path / "net.nsgw"
+    nsg.weights.save(str(path), nsg.weights.make_random(2, 64, seed=3, bn="random"))
+    base = ["--executor", "hip", "--weights", str(path), "--playouts", "24", "--max-games", "4", "--seed", "9",
+            "--threads", "1", "--games-per-group", "6"]
+    a = json.loads(run("selfplay", *base))
+    b = json.loads(run("selfplay", *base))
+    assert a["games_finished"] >= 4 and a["digest"] == b["digest"] and a["moves"] == b["moves"]
+    assert a["evals_per_sec"] > 0 and 0 <= a["cache_hit_ratio"] < 1
