@@ -99,6 +99,33 @@ def quick_rate(nsg, local_rank, blob, bb, B, precision, steps=5):
     return B * steps / dt
 
 
+SELFPLAY_BIN = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "selfplay", "selfplay")
+
+
+def selfplay_leg(weights_path, gpu, seconds, threads, precision, playouts=800, games_per_group=256):
+    """BASELINE metric #2 on this rank's GPU: the self-play driver (csrc/selfplay) with
+    the reference's option names/values of config 4 (--num-playouts 800, batch = games per
+    group).  games/sec = finished games / elapsed (saveworker.cc:135-137)."""
+    import subprocess
+    prec = {"fp32": 0, "fp16": 1, "bf16": 2, "f16x3": 3}[precision]
+    r = subprocess.run([SELFPLAY_BIN, "--executor", "hip", "--weights", weights_path, "--gpu", str(gpu),
+                        "--threads", str(threads), "--games-per-group", str(games_per_group),
+                        "--playouts", str(playouts), "--seconds", str(seconds), "--seed", "1",
+                        "--precision", str(prec)], capture_output=True, text=True, timeout=seconds * 3 + 300)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    return json.loads(r.stdout.strip().split("\n")[-1])
+
+
+def selfplay_cpu_baseline(seconds=8.0):
+    """BASELINE configs[0]: EXECUTOR=random CPU path, 1 MCTS thread, 100 playouts, startpos."""
+    import subprocess
+    r = subprocess.run([SELFPLAY_BIN, "--executor", "random", "--threads", "1", "--games-per-group", "1",
+                        "--playouts", "100", "--seconds", str(seconds), "--seed", "1"],
+                       capture_output=True, text=True, timeout=seconds * 3 + 60)
+    return json.loads(r.stdout.strip().split("\n")[-1]) if r.returncode == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +135,11 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--precision", default=os.environ.get("NSG_BENCH_PRECISION", "f16x3"),
                     choices=["fp32", "fp16", "bf16", "f16x3"])
+    ap.add_argument("--selfplay-seconds", type=float, default=30.0,
+                    help="length of the self-play leg (metric #2, games/sec); 0 disables it")
+    # BASELINE configs[3]: 256 concurrent games per GPU = 2 threads x 2 groups x 64 games
+    ap.add_argument("--selfplay-threads", type=int, default=2)
+    ap.add_argument("--selfplay-games-per-group", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     args = ap.parse_args()
@@ -169,6 +201,40 @@ def main():
     if distributed:
         dt = nsg.dist.max_over_ranks(dt, device="cuda")
 
+    # ---- metric #2: self-play games/sec (each rank drives its own GPU; games shard
+    # embarrassingly, no collective on the data path)
+    sp = None
+    if args.selfplay_seconds > 0 and os.path.exists(SELFPLAY_BIN):
+        wpath = f"/tmp/nsg_bench_weights_{os.getpid() if not distributed else 'shared'}.nsgw"
+        if rank == 0:
+            with open(wpath, "wb") as f:
+                f.write(blob)
+        barrier()
+        ev.close()  # free this process's evaluator before the self-play process allocates its own
+        mine = selfplay_leg(wpath, local_rank, args.selfplay_seconds, args.selfplay_threads, args.precision,
+                            games_per_group=args.selfplay_games_per_group)
+        keys = ("games_per_sec", "moves_per_sec", "playouts_per_sec", "evals_per_sec", "games_finished", "concurrent_games")
+        if "error" in mine:
+            sp = mine
+        else:
+            tot = {k: (nsg.dist.sum_over_ranks(mine[k], device="cuda") if distributed else mine[k]) for k in keys}
+            est = (tot["moves_per_sec"] / mine["avg_game_length"]) if mine["avg_game_length"] > 0 else None
+            sp = dict(tot, games_per_sec_steady_state_estimate=est, avg_batch=mine["avg_batch"], cache_hit_ratio=mine["cache_hit_ratio"],
+                      avg_game_length=mine["avg_game_length"], playouts_per_move=mine["playouts_per_move"],
+                      threads_per_gpu=mine["threads"], seconds=mine["seconds"],
+                      note="AlphaZero-mode self-play from startpos on this build's own shogi core; synthetic "
+                           "(untrained) weights, so games end early by repetition and the evaluation cache "
+                           "hits often: games/sec is a plumbing number, evals/playouts per sec are the load; "
+                           "games_per_sec is finished/elapsed from a cold start (saveworker.cc:135-137), the "
+                           "estimate is moves_per_sec / avg_game_length")
+        barrier()
+        if rank == 0:
+            try:
+                os.remove(wpath)
+            except OSError:
+                pass
+        ev = None
+
     out = None
     if rank == 0:
         evals = B * args.steps * world
@@ -201,7 +267,11 @@ def main():
             "forward_ms_hip_events": prof["forward_ms_total"] / max(prof["forwards"], 1),
             "device": info["device_name"], "compute_units": info["compute_units"],
         }
+        if sp is not None:
+            out["selfplay"] = sp
         if not args.no_host_path and world == 1:
+            ev = nsg.Evaluator(local_rank, B, 86, precision=args.precision)
+            ev.load_memory(blob)
             # the reference's own definition: computeBlocking incl. H2D/D2H (batchsize.cc:61-79)
             pol = np.empty((B, 2187), np.float32)
             win = np.empty(B, np.float32)
@@ -219,6 +289,8 @@ def main():
                 if p != args.precision}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+            if os.path.exists(SELFPLAY_BIN):
+                out["cpu_baseline"]["selfplay_random_1thread_100playouts"] = selfplay_cpu_baseline()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
