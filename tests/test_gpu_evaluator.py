@@ -195,3 +195,18 @@ def test_reduced_precision_paths(nsg, oracle, precision, tol):
     ref = oracle.net(blob).evaluate(bb)
     check(out, ref, tol)
     assert np.isfinite(out[0]).all()
+
+
+@pytest.mark.parametrize("env", [{"NSG_TRUNK_KERNEL": "1"}, {"NSG_CONV_NB": "1"}, {"NSG_CONV_NFRAG": "2"},
+                                 {"NSG_CONV_NFRAG": "1", "NSG_CONV_NB": "2"}])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_alternative_launch_plans_agree(nsg, oracle, monkeypatch, env, precision):
+    """The tuning knobs (persistent one-launch trunk, tile shapes) change the launch
+    plan, not the arithmetic: results stay within the oracle tolerance."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ev, blob = make(nsg, 2, 256, 70, precision=precision, seed=31)
+    bb = nsg.synth.random_batch(70, 86, seed=31)
+    p, v, d = ev.compute_blocking(bb)
+    idx = [0, 35, 69]
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), 2e-4)
