@@ -131,13 +131,25 @@ class Game {
         RootPly = S.ply();
         MoveList L;
         S.generateLegalMoves(L);
+        const bool Gumbel = Eng->Opt.Gumbel;
+        if (Gumbel) { // worker.cc:163-165, 640-648: one Gumbel(0,1) sample per root move
+            std::uniform_real_distribution<double> U(std::numeric_limits<double>::min(), 1.0);
+            for (int I = 0; I < 600; ++I) Noise[I] = -std::log(-std::log(U(Rng)));
+        }
         const double R = std::uniform_real_distribution<double>(0.0, 1.0)(Rng);
         if (L.size() == 1 || R > Eng->Opt.FullSearchRatio) {
-            Budget = L.size() == 1 ? 1u : (uint32_t)std::max(1, Eng->Opt.NumPlayouts / 4);
+            if (Gumbel) Budget = (uint32_t)Eng->Opt.NumSamplingMoves;
+            else Budget = L.size() == 1 ? 1u : (uint32_t)std::max(1, Eng->Opt.NumPlayouts / 4);
             FullSearch = false;
         } else {
             Budget = (uint32_t)Eng->Opt.NumPlayouts;
             FullSearch = true;
+        }
+        if (Gumbel) { // worker.cc:203-212
+            NumSampling = (uint32_t)Eng->Opt.NumSamplingMoves;
+            const double Init = std::floor((double)Budget / (std::log2((double)NumSampling) * (double)NumSampling));
+            HalvingPlayouts = (uint32_t)std::max(1.0, Init);
+            HalvingCount = 1;
         }
         Ph = Phase::LeafSelection;
     }
@@ -173,13 +185,95 @@ class Game {
         return BestEdge;
     }
 
+    Edge* pickGumbelRootEdge() const { // worker.cc:668-686: next target below the halving quota
+        for (uint16_t I = 0; I < Root->NumChildren; ++I) {
+            if (!IsTarget[I]) continue;
+            Edge* E = &Root->Edges[I];
+            if (E->Child == nullptr || E->Child->Visits < HalvingPlayouts) return E;
+        }
+        // every target already has its quota (can happen once the budget is spent): any target
+        for (uint16_t I = 0; I < Root->NumChildren; ++I)
+            if (IsTarget[I]) return &Root->Edges[I];
+        return &Root->Edges[0];
+    }
+
+    static double transformQ(double Q, uint32_t MaxN) { return (50.0 + (double)MaxN) * 1.0 * Q; } // worker.cc:654-659
+
+    double gumbelScore(uint16_t I) const {
+        const Edge* E = &Root->Edges[I];
+        return Noise[I] + (double)E->Prior + transformQ(winRateOfChild(S.sideToMove(), E->Child), E->Child->Visits);
+    }
+
+    void sampleTopMMoves() { // worker.cc:784-817
+        const uint16_t N = Root->NumChildren;
+        IsTarget.assign(N, true);
+        if (NumSampling >= N) return;
+        std::vector<std::pair<double, uint16_t>> Score(N);
+        for (uint16_t I = 0; I < N; ++I) Score[I] = {Noise[I] + (double)Root->Edges[I].Prior, I};
+        std::partial_sort(Score.begin(), Score.begin() + NumSampling, Score.end(),
+                          [](const auto& A, const auto& B) { return A.first > B.first; });
+        IsTarget.assign(N, false);
+        for (uint32_t I = 0; I < NumSampling; ++I) IsTarget[Score[I].second] = true;
+    }
+
+    uint16_t executeSequentialHalving() { // worker.cc:819-863
+        const uint16_t N = Root->NumChildren;
+        std::vector<std::pair<double, uint16_t>> Score(N);
+        for (uint16_t I = 0; I < N; ++I)
+            Score[I] = {IsTarget[I] ? gumbelScore(I) : std::numeric_limits<double>::lowest(), I};
+        std::size_t NumSort = std::min<std::size_t>(NumSampling, N);
+        NumSort = std::max<std::size_t>(2, (NumSort + 1) >> HalvingCount);
+        std::partial_sort(Score.begin(), Score.begin() + (long)NumSort, Score.end(),
+                          [](const auto& A, const auto& B) { return A.first > B.first; });
+        IsTarget.assign(N, false);
+        for (std::size_t I = 0; I < NumSort; ++I) IsTarget[Score[I].second] = true;
+        return (uint16_t)NumSort;
+    }
+
+    bool updateHalvingSchedule(uint16_t NumValid) { // worker.cc:865-905
+        const uint32_t MD = std::max<uint32_t>(1, NumSampling >> HalvingCount);
+        const double D = std::log2((double)NumSampling) * (double)MD;
+        const uint64_t Extra = (uint64_t)std::floor((double)Budget / D);
+        if (Extra == 0) return false;
+        if (NumValid <= 2) {
+            const uint64_t Left = (uint64_t)Budget + 1 - Root->Visits;
+            HalvingPlayouts += (uint32_t)((Left + 1) / 2);
+        } else {
+            HalvingPlayouts += (uint32_t)Extra;
+        }
+        ++HalvingCount;
+        return true;
+    }
+
+    // the Gumbel branch of worker.cc:412-475
+    void gumbelAfterBackprop() {
+        if (Root->NumChildren == 1) { Ph = Phase::Transition; return; }
+        if (Leaf == Root) {
+            sampleTopMMoves();
+        } else {
+            uint32_t MinN = std::numeric_limits<uint32_t>::max();
+            for (uint16_t I = 0; I < Root->NumChildren; ++I) {
+                if (!IsTarget[I]) continue;
+                const Node* Ch = Root->Edges[I].Child;
+                if (Ch == nullptr) { MinN = 0; break; }
+                MinN = std::min(MinN, Ch->Visits);
+            }
+            if (MinN >= HalvingPlayouts) {
+                if (Root->Visits >= Budget + 1) { Ph = Phase::Transition; return; }
+                const uint16_t NumValid = executeSequentialHalving();
+                if (!updateHalvingSchedule(NumValid)) { Ph = Phase::Transition; return; }
+            }
+        }
+        Ph = Phase::LeafSelection;
+    }
+
     void selectLeaf() { // worker.cc:217-266
         undoToRoot();
         Node* N = Root;
         for (;;) {
             if (N->Visits == 0 || N->NumChildren == 0 || N->Repetition != 0) break;
             if (S.ply() >= Config.MaxPly) break;
-            Edge* E = pickEdge(N);
+            Edge* E = (Eng->Opt.Gumbel && N == Root) ? pickGumbelRootEdge() : pickEdge(N);
             S.doMove(S.moveFrom16(E->Move16));
             if (!E->Child) {
                 E->Child = new Node();
@@ -243,6 +337,13 @@ class Game {
     // softmax over the legal-move logits, Dirichlet noise at a full-search root
     // (frame.cc:113-135), priors into the edges
     void finishEvaluation(uint16_t N, float Win, float Draw) {
+        if (Eng->Opt.Gumbel && Leaf == Root) { // frame.cc:116: a Gumbel root keeps the raw logits
+            for (uint16_t I = 0; I < N; ++I) Leaf->Edges[I].Prior = Logits[I];
+            Leaf->WinPred = Win;
+            Leaf->DrawPred = Draw;
+            Ph = Phase::Backpropagation;
+            return;
+        }
         float Max = -std::numeric_limits<float>::infinity();
         for (uint16_t I = 0; I < N; ++I) Max = std::max(Max, Logits[I]);
         float Sum = 0.f;
@@ -279,12 +380,26 @@ class Game {
         }
         undoToRoot();
         ++Eng->St.Playouts;
-        if (Root->NumChildren == 1 || Root->Visits >= Budget) Ph = Phase::Transition;
+        if (Eng->Opt.Gumbel) gumbelAfterBackprop();
+        else if (Root->NumChildren == 1 || Root->Visits >= Budget) Ph = Phase::Transition;
         else Ph = Phase::LeafSelection;
     }
 
     void transition() { // most visited move, ties by prior (worker.cc:562-596)
         undoToRoot();
+        if (Eng->Opt.Gumbel) { // worker.cc:598-638
+            Edge* Pick = &Root->Edges[0];
+            if (Root->NumChildren > 1) {
+                double BestScore = std::numeric_limits<double>::lowest();
+                for (uint16_t I = 0; I < Root->NumChildren; ++I) {
+                    if (!IsTarget[I] || Root->Edges[I].Child == nullptr || Root->Edges[I].Child->Visits == 0) continue;
+                    const double Sc = gumbelScore(I);
+                    if (Sc > BestScore) { BestScore = Sc; Pick = &Root->Edges[I]; }
+                }
+            }
+            playMove(S.moveFrom16(Pick->Move16));
+            return;
+        }
         uint32_t MaxVisits = 0;
         Edge* Best = nullptr;
         for (uint16_t I = 0; I < Root->NumChildren; ++I) {
@@ -302,7 +417,10 @@ class Game {
                 Best = E;
             }
         }
-        const Move M = S.moveFrom16(Best->Move16);
+        playMove(S.moveFrom16(Best->Move16));
+    }
+
+    void playMove(Move M) {
         S.doMove(M);
         ++GameMoves;
         ++Eng->St.Moves;
@@ -346,6 +464,9 @@ class Game {
     Phase Ph = Phase::RootPreparation;
     float Logits[600];
     double Noise[600];
+    // Gumbel state (frame.h: IsTarget, NumSamplingMoves, SequentialHalvingPlayouts/Count)
+    std::vector<bool> IsTarget;
+    uint32_t NumSampling = 16, HalvingPlayouts = 1, HalvingCount = 1;
 };
 
 struct Engine::Group {

@@ -14,6 +14,8 @@
 //   * every game has its own RNG seeded from (base seed, game serial) and batch
 //     results are slot-independent, so a run is reproducible bit for bit
 //     (the reference seeds from std::random_device, worker.cc:49-50);
+//   * Gumbel mode (worker.cc:428-475 sequential halving, :596-638 transition,
+//     :784-905 sampling / halving schedule) is implemented as in the reference;
 //   * the mate-in-3 dfs / df-pn solver calls (worker.cc:349-358,516-524) are not
 //     implemented: positions are searched instead;
 //   * the teacher record writer (saveworker.cc:160-182, libnshogi's SimpleTeacher
@@ -41,6 +43,8 @@ struct Options {
     int GamesPerGroup = 256;     // concurrent games per group (2 groups per engine)
     int NumPlayouts = 800;       // --num-playouts (selfplay/main.cc:43-45)
     double FullSearchRatio = 0.25; // --full-search-ratio (main.cc:54-55)
+    bool Gumbel = false;         // --gumbel: Gumbel AlphaZero root (sequential halving)
+    int NumSamplingMoves = 16;   // --num-sampling-moves ("m" of the paper, main.cc:46-48)
     uint64_t Seed = 0;
     int MaxPlyMin = 160 + 64;    // worker.cc:135-136
     int MaxPlyMax = 512 + 128;

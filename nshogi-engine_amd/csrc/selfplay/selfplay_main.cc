@@ -41,6 +41,8 @@ int main(int Argc, char* Argv[]) {
         else if (K == "--precision") Precision = std::stoi(V);
         else if (K == "--full-search-ratio") Opt.FullSearchRatio = std::stod(V);
         else if (K == "--cache-entries") Opt.EvalCacheEntries = std::stoull(V);
+        else if (K == "--gumbel") Opt.Gumbel = V != "0";
+        else if (K == "--num-sampling-moves") Opt.NumSamplingMoves = std::stoi(V);
         else { std::cerr << "unknown option " << K << std::endl; return 2; }
     }
     const bool Hip = Executor == "hip";
