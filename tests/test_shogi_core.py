@@ -80,6 +80,16 @@ def test_selfplay_cpu_random_executor_reproducible():
     assert a["black"] + a["white"] + a["draw"] == a["games_finished"]
 
 
+def test_selfplay_gumbel_mode_cpu():
+    """--gumbel (Gumbel AlphaZero root with sequential halving, worker.cc:428-475,784-905)."""
+    args = ["--executor", "random", "--threads", "1", "--games-per-group", "4", "--playouts", "64",
+            "--num-sampling-moves", "16", "--gumbel", "1", "--max-games", "3"]
+    a = json.loads(run("selfplay", *args, "--seed", 3))
+    b = json.loads(run("selfplay", *args, "--seed", 3))
+    assert a["games_finished"] >= 3 and a["digest"] == b["digest"]
+    assert a["playouts_per_sec"] > 0 and a["moves"] > 0
+
+
 @pytest.mark.gpu
 def test_selfplay_hip_reproducible(nsg, tmp_path):
     """Self-play on the HIP evaluator: move selection is bit-identical under a fixed
