@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -201,6 +202,14 @@ struct nsg_evaluator {
 
     void* trunkOut = nullptr; // which act[] holds the trunk output of the last forward
 
+    // chains: large batches run as independent half-batch launch chains
+    static constexpr int kMaxChains = 4;
+    hipStream_t chainStream[kMaxChains - 1] = {};
+    hipEvent_t forkEvent = nullptr;
+    hipEvent_t joinEvent[kMaxChains - 1] = {};
+    int numChains = 1;        // NSG_CHAINS (2 measured neutral, 4 slower: DESIGN.md)
+    int chainMinBatch = 512;  // NSG_CHAIN_MIN_BATCH
+
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev; // 4 per forward: fwd begin, trunk begin, trunk end, fwd end
@@ -267,10 +276,62 @@ int uploadLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int
 
 int roundUp(int a, int b) { return (a + b - 1) / b * b; }
 
+// One chain = the whole forward for boards [off, off + count) on stream `s`.
+int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& plan, hipStream_t s,
+                 bool stampsOk, hipEvent_t trunkBegin = nullptr, hipEvent_t trunkEnd = nullptr) {
+    const int prec = ev->prec;
+    const size_t es = (size_t)nsg::elemSize(prec);
+    auto act = [&](void* base, size_t rowElems) { return (void*)((unsigned char*)base + (size_t)off * rowElems * es); };
+    const uint64_t* input = (const uint64_t*)ev->input.p + (size_t)off * ev->numChannels * 2;
+    void* planes = act(ev->planes.p, (size_t)81 * ev->cpad);
+    // feature planes (replaces cuda::extractBits, trt.cc:255-258)
+    NSG_HIP(nsg::launchExtractBitsAct(planes, input, count, ev->numChannels, ev->cpad, prec, s));
+    // stem + residual trunk
+    void* x = act(ev->act[0].p, (size_t)81 * ev->F);
+    void* y = act(ev->act[1].p, (size_t)81 * ev->F);
+    void* z = act(ev->act[2].p, (size_t)81 * ev->F);
+    if (ev->useTrunkKernel && off == 0 && count == 0x7fffffff) {
+        // (unreachable: the persistent trunk runs through enqueueForward's single-chain path)
+    }
+    NSG_HIP(nsg::launchConv3x3(planes, ev->stem.w.p, (const float*)ev->stem.bias.p, nullptr, x, count,
+                               ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s, ev->ntStore));
+    if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
+    for (int k = 0; k < ev->blocks; ++k) {
+        unsigned long long* st1 = nullptr;
+        unsigned long long* st2 = nullptr;
+#ifdef NSG_DIAG_STAMPS
+        if (ev->stamps.p && stampsOk) {
+            st1 = (unsigned long long*)ev->stamps.p + (size_t)(2 * k) * 4096 * 8;
+            st2 = (unsigned long long*)ev->stamps.p + (size_t)(2 * k + 1) * 4096 * 8;
+        }
+#else
+        (void)stampsOk;
+#endif
+        NSG_HIP(nsg::launchConv3x3(x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p, nullptr, y, count,
+                                   ev->F, ev->F, 1, ev->conv1[k].accScale, prec, plan, s, ev->ntStore, st1));
+        NSG_HIP(nsg::launchConv3x3(y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p, x, z, count,
+                                   ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s, ev->ntStore, st2));
+        void* t = x; x = z; z = t;
+    }
+    if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
+    if (off == 0) ev->trunkOut = x;
+    // heads
+    float* policy = (float*)ev->policy.p + (size_t)off * NSG_MOVE_INDEX_MAX;
+    void* vfeat = act(ev->vfeat.p, (size_t)ev->fc1K);
+    float* hidden = (float*)ev->hidden.p + (size_t)off * ev->vh;
+    NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p, policy, vfeat, count, ev->F,
+                             ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, prec, s));
+    NSG_HIP(nsg::launchDense(vfeat, ev->fc1.w.p, (const float*)ev->fc1.bias.p, hidden, count, ev->fc1K,
+                             ev->vh, 1, ev->fc1.accScale, prec, s));
+    NSG_HIP(nsg::launchValueOut(hidden, (const float*)ev->fc2W.p, (const float*)ev->fc2B.p,
+                                (float*)ev->value.p + off, (float*)ev->draw.p + off, count, ev->vh, s));
+    return NSG_OK;
+}
+
 int enqueueForward(nsg_evaluator* ev, size_t n) {
     const int B = (int)n;
-    const int prec = ev->prec;
     hipStream_t s = ev->stream;
+    // the tile plan is chosen for the whole batch: all chains run concurrently
     const nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount);
 
     const bool prof = ev->profile;
@@ -281,49 +342,51 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     hipEvent_t* e = prof ? &ev->ev[ev->evUsed] : nullptr;
     if (prof) NSG_HIP(hipEventRecord(e[0], s));
 
-    // feature planes (replaces cuda::extractBits, trt.cc:255-258)
-    NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, B,
-                                      ev->numChannels, ev->cpad, prec, s));
-    // stem + residual trunk
-    void* x = ev->act[0].p;
-    void* y = ev->act[1].p;
-    void* z = ev->act[2].p;
-    if (ev->useTrunkKernel && nsg::canRunTrunk(ev->F, plan)) {
-        // one persistent launch for all 2N+1 3x3 layers (buffers rotate as below)
+    // Large batches run as independent chains of half-batch launches on separate
+    // streams: boards never interact, so chain A's layer l+1 may start while chain B
+    // is still in layer l.  Kernel-boundary tails and the epilogue's HBM bursts of one
+    // chain overlap the other chain's MFMA phase instead of idling the whole chip.
+    int chains = (B >= ev->chainMinBatch && plan.nb == 2) ? ev->numChains : 1;
+    if (ev->useTrunkKernel && nsg::canRunTrunk(ev->F, plan)) chains = 1;
+    const int per = ((B + chains - 1) / chains + 1) / 2 * 2; // boards per chain, whole 2-board tiles
+
+    if (chains == 1 && ev->useTrunkKernel && nsg::canRunTrunk(ev->F, plan)) {
+        // one persistent launch for all 2N+1 3x3 layers (measured slower; NSG_TRUNK_KERNEL=1)
+        const int prec = ev->prec;
+        NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, B, ev->numChannels,
+                                          ev->cpad, prec, s));
         if (prof) NSG_HIP(hipEventRecord(e[1], s));
         NSG_HIP(nsg::launchTrunk(ev->trunkLayers.p, ev->trunkLayerCount, B, prec, plan, s));
-        if (ev->blocks % 2 == 1) x = z; // the output buffer alternates act[0] / act[2]
+        if (prof) NSG_HIP(hipEventRecord(e[2], s));
+        void* x = (ev->blocks % 2 == 1) ? ev->act[2].p : ev->act[0].p;
+        ev->trunkOut = x;
+        NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p, (float*)ev->policy.p,
+                                 ev->vfeat.p, B, ev->F, ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, prec, s));
+        NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->fc1.w.p, (const float*)ev->fc1.bias.p, (float*)ev->hidden.p,
+                                 B, ev->fc1K, ev->vh, 1, ev->fc1.accScale, prec, s));
+        NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->fc2W.p, (const float*)ev->fc2B.p,
+                                    (float*)ev->value.p, (float*)ev->draw.p, B, ev->vh, s));
+    } else if (chains == 1) {
+        int rc = enqueueChain(ev, 0, B, plan, s, true, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
+        if (rc) return rc;
     } else {
-        NSG_HIP(nsg::launchConv3x3(ev->planes.p, ev->stem.w.p, (const float*)ev->stem.bias.p,
-                                   nullptr, x, B, ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s, ev->ntStore));
+        NSG_HIP(hipEventRecord(ev->forkEvent, s));
         if (prof) NSG_HIP(hipEventRecord(e[1], s));
-        for (int k = 0; k < ev->blocks; ++k) {
-            unsigned long long* st1 = nullptr;
-            unsigned long long* st2 = nullptr;
-#ifdef NSG_DIAG_STAMPS
-            if (ev->stamps.p) {
-                st1 = (unsigned long long*)ev->stamps.p + (size_t)(2 * k) * 4096 * 8;
-                st2 = (unsigned long long*)ev->stamps.p + (size_t)(2 * k + 1) * 4096 * 8;
+        for (int c = 0; c < chains; ++c) {
+            const int off = c * per;
+            const int count = std::min(per, B - off);
+            if (count <= 0) break;
+            hipStream_t cs = (c == 0) ? s : ev->chainStream[c - 1];
+            if (c > 0) NSG_HIP(hipStreamWaitEvent(cs, ev->forkEvent, 0));
+            int rc = enqueueChain(ev, off, count, plan, cs, c == 0);
+            if (rc) return rc;
+            if (c > 0) {
+                NSG_HIP(hipEventRecord(ev->joinEvent[c - 1], cs));
+                NSG_HIP(hipStreamWaitEvent(s, ev->joinEvent[c - 1], 0));
             }
-#endif
-            NSG_HIP(nsg::launchConv3x3(x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p,
-                                       nullptr, y, B, ev->F, ev->F, 1, ev->conv1[k].accScale, prec, plan, s, ev->ntStore, st1));
-            NSG_HIP(nsg::launchConv3x3(y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p,
-                                       x, z, B, ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s, ev->ntStore, st2));
-            void* t = x; x = z; z = t;
         }
+        if (prof) NSG_HIP(hipEventRecord(e[2], s));
     }
-    if (prof) NSG_HIP(hipEventRecord(e[2], s));
-    ev->trunkOut = x;
-    // heads
-    NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p,
-                             (float*)ev->policy.p, ev->vfeat.p, B, ev->F, ev->headsCout,
-                             ev->vc, ev->fc1K, ev->heads.accScale, prec, s));
-    NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->fc1.w.p, (const float*)ev->fc1.bias.p,
-                             (float*)ev->hidden.p, B, ev->fc1K, ev->vh, 1, ev->fc1.accScale, prec, s));
-    NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->fc2W.p,
-                                (const float*)ev->fc2B.p, (float*)ev->value.p,
-                                (float*)ev->draw.p, B, ev->vh, s));
     if (prof) {
         NSG_HIP(hipEventRecord(e[3], s));
         ev->evUsed += 4;
@@ -372,6 +435,14 @@ int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator**
     if ((rc = ev->draw.alloc((size_t)batch_size_max * 4, true))) return rc;
     // trt.cc:79
     NSG_HIP(hipStreamCreateWithFlags(&ev->stream, hipStreamNonBlocking));
+    for (auto& cs : ev->chainStream) NSG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    NSG_HIP(hipEventCreateWithFlags(&ev->forkEvent, hipEventDisableTiming));
+    for (auto& je : ev->joinEvent) NSG_HIP(hipEventCreateWithFlags(&je, hipEventDisableTiming));
+    if (const char* e2 = getenv("NSG_CHAINS")) {
+        const int v = atoi(e2);
+        if (v >= 1 && v <= nsg_evaluator::kMaxChains) ev->numChains = v;
+    }
+    if (const char* e2 = getenv("NSG_CHAIN_MIN_BATCH")) ev->chainMinBatch = std::max(2, atoi(e2));
     *out = ev.release();
     return NSG_OK;
 }
@@ -383,6 +454,11 @@ int nsg_destroy(nsg_evaluator* ev) {
         (void)hipStreamSynchronize(ev->stream);
     }
     for (hipEvent_t e : ev->ev) (void)hipEventDestroy(e);
+    for (auto cs : ev->chainStream)
+        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+    if (ev->forkEvent) (void)hipEventDestroy(ev->forkEvent);
+    for (auto je : ev->joinEvent)
+        if (je) (void)hipEventDestroy(je);
     if (ev->stream) (void)hipStreamDestroy(ev->stream);
     delete ev;
     return NSG_OK;
