@@ -13,7 +13,10 @@ ConvPlan chooseConvPlan(int batch, int cout, int computeUnits) {
     // Full tiles: 4 fragments (64 channels) per wave, widest workgroup that divides
     // the channel groups (its waves share one LDS image of the input tile).
     p.nfrag = kNfrag;
-    p.nwaves = (groups % 4 == 0) ? 4 : (groups % 3 == 0) ? 3 : (groups % 2 == 0) ? 2 : 1;
+    // A full tile's wave needs the whole register file of its SIMD, so a CU hosts
+    // 4 waves: one 4-wave workgroup or two 2-wave workgroups fill it, a 3-wave
+    // workgroup leaves a SIMD idle (40x384: 2-wave groups +17 % over 3-wave groups).
+    p.nwaves = (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : (groups % 3 == 0) ? 3 : 1;
     // Two boards per workgroup waste less of the last 16-row fragment (162 -> 176
     // rows vs 81 -> 96) but halve the grid: use them once the grid still covers
     // most of the chip.
@@ -39,10 +42,14 @@ chosen:
         const int v = atoi(e);
         if (v == 1 || v == 2) p.nb = v;
     }
+    if (const char* e = getenv("NSG_CONV_NWAVES")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4 && groups % v == 0 && p.nfrag == kNfrag) p.nwaves = v;
+    }
     if (const char* e = getenv("NSG_CONV_NFRAG")) {
         const int v = atoi(e);
         if (v == 1 || v == 2) { p.nfrag = v; p.nwaves = 4; }
-        if (v == 4) { p.nfrag = 4; p.nwaves = (groups % 4 == 0) ? 4 : (groups % 3 == 0) ? 3 : (groups % 2 == 0) ? 2 : 1; }
+        if (v == 4) { p.nfrag = 4; p.nwaves = (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : (groups % 3 == 0) ? 3 : 1; }
     }
     return p;
 }
