@@ -209,13 +209,6 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     // kConv buffers are sized for whole workgroups; flat modes clamp rows.
     const size_t lastRow = G::kBoards ? ~(size_t)0 : (size_t)(A.totalRows - 1);
 
-    if (G::kBoards && zeroLds) {
-        // zero the LDS image: halo entries stay zero for the whole kernel
-        for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
-            reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-
     // per-lane LDS read bases of the row fragments
     int abase[G::kMF];
 #pragma unroll
@@ -298,6 +291,13 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         for (int j = 0; j < NFRAG; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     NSG_STAGE_LOAD(0)
+    if (G::kBoards && zeroLds) {
+        // zero the LDS image (halo entries stay zero for the whole kernel) while the
+        // first tile and the first weight slabs are in flight
+        for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
+            reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
     if constexpr (G::kBoards) __syncthreads(); // zero fill done before staging writes
     NSG_STAGE_WRITE(0)
     __syncthreads();
