@@ -57,7 +57,7 @@ inline int paddedBoards(int batch, int nb) { return (batch + nb - 1) / nb * nb; 
 hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
                          const void* residual, void* y, int batch, int cin,
                          int cout, int relu, float accScale, int prec,
-                         const ConvPlan& plan, hipStream_t stream, int ntStore = 0,
+                         const ConvPlan& plan, hipStream_t stream,
                          unsigned long long* stamps = nullptr);
 
 // Persistent trunk: every 3x3 layer (stem + 2 per block) in ONE launch.  A layer
@@ -67,7 +67,7 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
 size_t trunkLayerBytes();
 void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfrag,
                     const float* bias, const void* residual, void* y, int cin,
-                    int cout, int relu, float accScale, int ntStore);
+                    int cout, int relu, float accScale);
 bool canRunTrunk(int cout, const ConvPlan& plan);
 hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
                        const ConvPlan& plan, hipStream_t stream);

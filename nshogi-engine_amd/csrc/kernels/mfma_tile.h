@@ -161,7 +161,6 @@ struct Args {
     int valueChannels;        // kHeads: channels [0,VC) = value conv, [VC,VC+27) = policy
     int vfeatStride;          // kHeads: elements per board row of vfeat (>= 81*VC)
     float accScale;           // accumulators are multiplied by this before the bias (kF16x3: 1/weight scale)
-    int ntStore;              // reserved (non-temporal output stores measured no gain)
     unsigned long long* stamps; // diagnostic builds only (NSG_DIAG_STAMPS): 8 u64 per workgroup
 };
 

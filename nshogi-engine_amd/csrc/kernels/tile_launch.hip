@@ -38,16 +38,14 @@ ConvPlan chooseConvPlan(int batch, int cout, int computeUnits) {
         }
     }
 chosen:
-    if (const char* e = getenv("NSG_CONV_NB")) { // tuning knobs
-        const int v = atoi(e);
-        if (v == 1 || v == 2) p.nb = v;
-    }
-    if (const char* e = getenv("NSG_CONV_NWAVES")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 4 && groups % v == 0 && p.nfrag == kNfrag) p.nwaves = v;
-    }
-    if (const char* e = getenv("NSG_CONV_NFRAG")) {
-        const int v = atoi(e);
+    // tuning knobs (read once per process)
+    static const int kEnvNb = [] { const char* e = getenv("NSG_CONV_NB"); return e ? atoi(e) : 0; }();
+    static const int kEnvNwaves = [] { const char* e = getenv("NSG_CONV_NWAVES"); return e ? atoi(e) : 0; }();
+    static const int kEnvNfrag = [] { const char* e = getenv("NSG_CONV_NFRAG"); return e ? atoi(e) : 0; }();
+    if (kEnvNb == 1 || kEnvNb == 2) p.nb = kEnvNb;
+    if (kEnvNwaves >= 1 && kEnvNwaves <= 4 && groups % kEnvNwaves == 0 && p.nfrag == kNfrag) p.nwaves = kEnvNwaves;
+    if (kEnvNfrag) {
+        const int v = kEnvNfrag;
         if (v == 1 || v == 2) { p.nfrag = v; p.nwaves = 4; }
         if (v == 4) { p.nfrag = 4; p.nwaves = (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : (groups % 3 == 0) ? 3 : 1; }
     }
@@ -57,7 +55,7 @@ chosen:
 hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
                          const void* residual, void* y, int batch, int cin,
                          int cout, int relu, float accScale, int prec,
-                         const ConvPlan& plan, hipStream_t stream, int ntStore,
+                         const ConvPlan& plan, hipStream_t stream,
                          unsigned long long* stamps) {
     if (batch <= 0 || (cin * elemSize(prec)) % 128 != 0 || cout % 64 != 0)
         return hipErrorInvalidValue;
@@ -72,7 +70,6 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
     a.totalRows = batch * 81;
     a.relu = relu;
     a.accScale = accScale;
-    a.ntStore = ntStore;
     a.stamps = stamps;
     switch (prec) {
     case kFp32: return tile::launchConvFp32(a, batch, plan, stream);
@@ -87,9 +84,8 @@ size_t trunkLayerBytes() { return sizeof(tile::Args); }
 
 void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfrag,
                     const float* bias, const void* residual, void* y, int cin,
-                    int cout, int relu, float accScale, int ntStore) {
+                    int cout, int relu, float accScale) {
     tile::Args a{};
-    a.ntStore = ntStore;
     a.x = (const unsigned char*)x;
     a.w = (const tile::u32x4*)wfrag;
     a.bias = bias;

@@ -198,7 +198,6 @@ struct nsg_evaluator {
     DevBuf trunkLayers;      // persistent-trunk layer list (stem + 2 per block)
     int trunkLayerCount = 0;
     bool useTrunkKernel = false; // NSG_TRUNK_KERNEL=1: one persistent launch for all 3x3 layers (measured slower)
-    int ntStore = 0;             // NSG_NT_STORE=1: non-temporal activation stores (experiment)
 
     void* trunkOut = nullptr; // which act[] holds the trunk output of the last forward
 
@@ -290,11 +289,8 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     void* x = act(ev->act[0].p, (size_t)81 * ev->F);
     void* y = act(ev->act[1].p, (size_t)81 * ev->F);
     void* z = act(ev->act[2].p, (size_t)81 * ev->F);
-    if (ev->useTrunkKernel && off == 0 && count == 0x7fffffff) {
-        // (unreachable: the persistent trunk runs through enqueueForward's single-chain path)
-    }
     NSG_HIP(nsg::launchConv3x3(planes, ev->stem.w.p, (const float*)ev->stem.bias.p, nullptr, x, count,
-                               ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s, ev->ntStore));
+                               ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s));
     if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
     for (int k = 0; k < ev->blocks; ++k) {
         unsigned long long* st1 = nullptr;
@@ -308,9 +304,9 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
         (void)stampsOk;
 #endif
         NSG_HIP(nsg::launchConv3x3(x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p, nullptr, y, count,
-                                   ev->F, ev->F, 1, ev->conv1[k].accScale, prec, plan, s, ev->ntStore, st1));
+                                   ev->F, ev->F, 1, ev->conv1[k].accScale, prec, plan, s, st1));
         NSG_HIP(nsg::launchConv3x3(y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p, x, z, count,
-                                   ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s, ev->ntStore, st2));
+                                   ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s, st2));
         void* t = x; x = z; z = t;
     }
     if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
@@ -544,19 +540,16 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
     if ((rc = ev->vfeat.alloc((size_t)ev->batchMax * ev->fc1K * es, true))) return rc;
     if ((rc = ev->hidden.alloc((size_t)ev->batchMax * nv.vh * 4, true))) return rc;
     {   // persistent-trunk layer list, same buffer rotation as the per-layer path
-        const char* envNt = getenv("NSG_NT_STORE");
-        ev->ntStore = (envNt && envNt[0] == '1') ? 1 : 0;
-        const int nt = ev->ntStore;
         const int nl = 1 + 2 * nv.blocks;
         std::vector<unsigned char> host((size_t)nl * nsg::trunkLayerBytes());
         void* x = ev->act[0].p; void* y = ev->act[1].p; void* z = ev->act[2].p;
         nsg::fillTrunkLayer(host.data(), 0, ev->planes.p, ev->stem.w.p, (const float*)ev->stem.bias.p,
-                            nullptr, x, ev->cpad, nv.F, 1, ev->stem.accScale, nt);
+                            nullptr, x, ev->cpad, nv.F, 1, ev->stem.accScale);
         for (int k = 0; k < nv.blocks; ++k) {
             nsg::fillTrunkLayer(host.data(), 1 + 2 * k, x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p,
-                                nullptr, y, nv.F, nv.F, 1, ev->conv1[k].accScale, nt);
+                                nullptr, y, nv.F, nv.F, 1, ev->conv1[k].accScale);
             nsg::fillTrunkLayer(host.data(), 2 + 2 * k, y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p,
-                                x, z, nv.F, nv.F, 1, ev->conv2[k].accScale, nt);
+                                x, z, nv.F, nv.F, 1, ev->conv2[k].accScale);
             void* t = x; x = z; z = t;
         }
         if ((rc = ev->trunkLayers.alloc(host.size(), false))) return rc;

@@ -210,10 +210,6 @@ bool State::attackedWithout(int Sq, Color By, int RemovedSq, int AddedSq) const 
     return false;
 }
 
-int State::attackersTo(int Sq, Color By, int IgnoreSq) const {
-    return attackedWithout(Sq, By, IgnoreSq, -1) ? 1 : 0;
-}
-
 // ---------------------------------------------------------------------------
 // move generation
 // ---------------------------------------------------------------------------
@@ -382,8 +378,11 @@ void State::generateLegalMoves(MoveList& Out) const {
 // iff the opponent then has no legal move.  (The reply generator cannot recurse: the
 // checker is a contact pawn, so the replies contain no drops.)
 bool State::isPawnDropMate(int To) const {
-    State Tmp(*this);
-    Tmp.History.clear();
+    State Tmp(0); // board-only copy: the (possibly long) move history is not needed
+    std::memcpy(Tmp.Board, Board, sizeof(Board));
+    std::memcpy(Tmp.Hands, Hands, sizeof(Hands));
+    Tmp.KingSq[0] = KingSq[0];
+    Tmp.KingSq[1] = KingSq[1];
     Tmp.put(To, makePiece(Side, Pawn));
     --Tmp.Hands[Side][Pawn];
     Tmp.Side = ~Side;

@@ -112,7 +112,7 @@ class State {
     void generateLegalMovesSlow(MoveList& Out);
 
     bool inCheck() const { return isAttacked(KingSq[Side], ~Side); }
-    bool isAttacked(int Sq, Color By) const { return attackersTo(Sq, By, -1) != 0; }
+    bool isAttacked(int Sq, Color By) const { return attackedWithout(Sq, By, -1, -1); }
 
     // Fourfold repetition.  With CheckPerpetual, a repetition whose every move by one
     // side was a check is a loss for that side: Win/Loss are from the side to move.
@@ -131,9 +131,6 @@ class State {
         uint64_t HashBefore;  // position hash before the move
         bool WasCheck;        // the move gave check
     };
-    // bit i of the result = "a By piece on square list index i attacks Sq" is not needed;
-    // returns the number of attackers, stops at `Limit` if >= 0 ... (count only)
-    int attackersTo(int Sq, Color By, int IgnoreSq) const;
     bool attackedWithout(int Sq, Color By, int RemovedSq, int AddedSq) const;
     bool isPawnDropMate(int To) const;
     void put(int Sq, Piece P);
