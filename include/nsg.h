@@ -168,6 +168,12 @@ typedef struct nsg_info {
 } nsg_info;
 int nsg_get_info(nsg_evaluator* ev, nsg_info* info);
 
+/* Launch plan of the most recent forward pass (tests and tuning): boards per
+ * workgroup, 16-channel fragments per wave, waves per workgroup, and the number
+ * of independent half-batch chains.  All zero before the first forward pass. */
+int nsg_get_last_plan(nsg_evaluator* ev, int* boards_per_group, int* fragments_per_wave,
+                      int* waves_per_group, int* chains);
+
 /* CPU stand-in executors of the reference (src/infer/zero.cc, nothing.cc,
  * random.cc): product code, selectable like EXECUTOR=zero|nothing|random
  * (Makefile:107-121).  kind: 0 = Zero, 1 = Nothing, 2 = Random(seed). */

@@ -92,6 +92,8 @@ def load_library():
                                      ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_uint64)]
     lib.nsg_get_info.argtypes = [vp, ctypes.POINTER(_Info)]
+    ip = ctypes.POINTER(ctypes.c_int)
+    lib.nsg_get_last_plan.argtypes = [vp, ip, ip, ip, ip]
     lib.nsg_cpu_executor_create.argtypes = [i, ctypes.c_uint64, ctypes.POINTER(vp)]
     lib.nsg_cpu_executor_destroy.argtypes = [vp]
     lib.nsg_cpu_executor_compute.argtypes = [vp, vp, sz, vp, vp, vp]
@@ -231,6 +233,13 @@ class Evaluator:
         d = {k: getattr(s, k) for k, _ in _Info._fields_}
         d["device_name"] = s.device_name.decode("utf-8", "replace")
         return d
+
+    def last_plan(self):
+        """Launch plan of the most recent forward pass (nsg_get_last_plan)."""
+        v = [ctypes.c_int() for _ in range(4)]
+        _check(self._lib.nsg_get_last_plan(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("boards_per_group", "fragments_per_wave", "waves_per_group", "chains"),
+                        (x.value for x in v)))
 
 
 class CpuExecutor:

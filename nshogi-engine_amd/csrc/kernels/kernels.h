@@ -47,8 +47,15 @@ struct ConvPlan {
 };
 constexpr int kNfrag = 4; // every packed tensor uses 4 fragments (64 channels) per wave
 
+// Tuning overrides (0 = automatic), read from NSG_CONV_NB / _NWAVES / _NFRAG when an
+// evaluator is created.
+struct ConvTuning {
+    int nb = 0, nwaves = 0, nfrag = 0;
+};
+ConvTuning readConvTuning();
+
 // Picks a tile configuration for (batch, cout).
-ConvPlan chooseConvPlan(int batch, int cout, int computeUnits);
+ConvPlan chooseConvPlan(int batch, int cout, int computeUnits, const ConvTuning& tune = ConvTuning());
 
 // 3x3 convolution + folded-BN bias (+ residual) (+ ReLU) on
 // activations [boards][81][cin] -> [boards][81][cout].  Buffers must hold

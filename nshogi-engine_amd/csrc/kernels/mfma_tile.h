@@ -303,34 +303,83 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 
     NSG_STAMP(1);
     u32x4 a[kRingA][G::kMF]; // row fragments: current slab + the next kRingA-1
+    // Long chunks (3x3 taps) run one continuous slab pipeline across chunk boundaries:
+    // the next chunk's tile is written to the other LDS buffer a third of the way into
+    // the chunk, the barrier that publishes it sits kRingA slabs before the end, and the
+    // last slabs already request the next chunk's first row fragments -- no drain, no
+    // LDS write latency and no cold fragment read between chunks.
+    constexpr bool kFlow = (kSlabs >= 9);
+    // kF16x3 with a two-deep fragment ring: slabs (w_hi,x_hi) and (w_lo,x_hi) of a tap
+    // share their row fragments, so a tap needs two fragment loads (hi -> a[0] during the
+    // previous tap's last slab, lo -> a[1] during this tap's first slab), not three.
+    constexpr bool kSlot = kFlow && kSplit && (kRingA == 2);
+    static_assert(!kFlow || kSlot || kSlabs % kRingA == 0, "ring slot must carry across chunks");
+    constexpr int kWriteSlab = kSlot ? 3 * (G::kTaps / 3) + 1 : kSlabs / 3;
+    constexpr int kBarSlab = kSlot ? kSlabs - 2 : kSlabs - kRingA + 1; // barrier at the top of this slab
+    if constexpr (kFlow) {
+#pragma unroll
+        for (int q = 0; q < (kSlot ? 1 : kRingA - 1); ++q)
+#pragma unroll
+            for (int f = 0; f < G::kMF; ++f) a[q][f] = *reinterpret_cast<const u32x4*>(smem + abase[f] + slabOff(q));
+    }
     for (int kc = 0; kc < nkc; ++kc) {
         const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
+        const unsigned char* nbuf = smem + ((kc + 1) & 1) * G::kBuf;
+        if constexpr (!kFlow) {
 #pragma unroll
-        for (int q = 0; q < kRingA - 1; ++q) // first slabs of this chunk (just published by the barrier)
+            for (int q = 0; q < kRingA - 1; ++q) // first slabs of this chunk (just published by the barrier)
 #pragma unroll
-            for (int f = 0; f < G::kMF; ++f)
-                if (q < kSlabs) a[q][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + slabOff(q));
-        // next chunk's tile: global -> registers now, registers -> LDS after the last slab
+                for (int f = 0; f < G::kMF; ++f)
+                    if (q < kSlabs) a[q][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + slabOff(q));
+        }
+        // next chunk's tile: global -> registers now, registers -> LDS later
         // (the last iteration re-loads its own chunk: harmless, keeps st[] in registers)
         NSG_STAGE_LOAD(kc + 1 < nkc ? kc + 1 : kc)
 #pragma unroll
         for (int s = 0; s < kSlabs; ++s) {
+            if constexpr (kFlow) {
+                if (s == kWriteSlab) { NSG_STAGE_WRITE((kc + 1) & 1) }
+                if (s == kBarSlab) __syncthreads();
+            }
             // -- requests for later slabs
-            if (s + kRingA - 1 < kSlabs) {
+            bool dsReads = true;
+            if constexpr (kSlot) {
+                const int r = s % 3;
+                dsReads = (r != 1);
+                if (r == 0) { // this tap's lo fragments
+                    const int off1 = slabOff(s + 2);
+#pragma unroll
+                    for (int f = 0; f < G::kMF; ++f)
+                        a[1][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + off1);
+                } else if (r == 2) { // next tap's hi fragments (after the last tap: next chunk's)
+                    const unsigned char* src = (s + 1 < kSlabs) ? abuf : nbuf;
+                    const int off1 = slabOff((s + 1) % kSlabs);
+#pragma unroll
+                    for (int f = 0; f < G::kMF; ++f)
+                        a[0][f] = *reinterpret_cast<const u32x4*>(src + abase[f] + off1);
+                }
+            } else if (s + kRingA - 1 < kSlabs) {
                 const int off1 = slabOff(s + kRingA - 1);
 #pragma unroll
                 for (int f = 0; f < G::kMF; ++f)
                     a[(s + kRingA - 1) % kRingA][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + off1);
+            } else if constexpr (kFlow) {
+                // first slabs of the next chunk (after the last chunk: a harmless re-read)
+                const int off1 = slabOff(s + kRingA - 1 - kSlabs);
+#pragma unroll
+                for (int f = 0; f < G::kMF; ++f)
+                    a[(s + kRingA - 1) % kRingA][f] = *reinterpret_cast<const u32x4*>(nbuf + abase[f] + off1);
             }
             if constexpr (kRing >= 3) {
 #pragma unroll
                 for (int j = 0; j < NFRAG; ++j) w[(s + kRing - 1) % kRing][j] = wp[j * 64];
             }
             // -- this slab's MFMAs
+            const int aslot = kSlot ? (s % 3 == 2 ? 1 : 0) : s % kRingA;
 #pragma unroll
             for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w[s % kRing][j], a[s % kRingA][f]);
+                for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w[s % kRing][j], a[aslot][f]);
             if constexpr (kRing == 2) {
 #pragma unroll
                 for (int j = 0; j < NFRAG; ++j) w[s % 2][j] = wp[j * 64];
@@ -340,16 +389,21 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 // interleave: one LDS read (+ one weight load) per NFRAG row-fragment MFMAs
 #pragma unroll
                 for (int f = 0; f < G::kMF; ++f) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
+                    if (dsReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
                     if (f < NFRAG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
+                    if (kFlow && s == kWriteSlab && f < G::kItems)
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); // DS write
                     __builtin_amdgcn_sched_group_barrier(0x008, NFRAG * kMfmaPerPair, 0); // MFMA
                 }
             }
             __builtin_amdgcn_sched_barrier(0); // nothing sinks out of its slab
         }
-        NSG_STAGE_WRITE((kc + 1) & 1)
-        __syncthreads();
+        if constexpr (!kFlow) {
+            NSG_STAGE_WRITE((kc + 1) & 1)
+            __syncthreads();
+        }
     }
+    if constexpr (kFlow) __syncthreads(); // every wave is done reading before the epilogue reuses LDS
 
 #undef NSG_STAGE_LOAD
 #undef NSG_STAGE_WRITE

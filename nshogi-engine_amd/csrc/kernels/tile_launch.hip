@@ -7,7 +7,15 @@
 
 namespace nsg {
 
-ConvPlan chooseConvPlan(int batch, int cout, int computeUnits) {
+ConvTuning readConvTuning() {
+    ConvTuning t;
+    if (const char* e = getenv("NSG_CONV_NB")) t.nb = atoi(e);
+    if (const char* e = getenv("NSG_CONV_NWAVES")) t.nwaves = atoi(e);
+    if (const char* e = getenv("NSG_CONV_NFRAG")) t.nfrag = atoi(e);
+    return t;
+}
+
+ConvPlan chooseConvPlan(int batch, int cout, int computeUnits, const ConvTuning& tune) {
     ConvPlan p;
     const int groups = cout / (kNfrag * 16); // 64-channel weight groups
     // Full tiles: 4 fragments (64 channels) per wave, widest workgroup that divides
@@ -38,17 +46,14 @@ ConvPlan chooseConvPlan(int batch, int cout, int computeUnits) {
         }
     }
 chosen:
-    // tuning knobs (read once per process)
-    static const int kEnvNb = [] { const char* e = getenv("NSG_CONV_NB"); return e ? atoi(e) : 0; }();
-    static const int kEnvNwaves = [] { const char* e = getenv("NSG_CONV_NWAVES"); return e ? atoi(e) : 0; }();
-    static const int kEnvNfrag = [] { const char* e = getenv("NSG_CONV_NFRAG"); return e ? atoi(e) : 0; }();
+    const int kEnvNb = tune.nb, kEnvNwaves = tune.nwaves, kEnvNfrag = tune.nfrag;
     if (kEnvNb == 1 || kEnvNb == 2) p.nb = kEnvNb;
-    if (kEnvNwaves >= 1 && kEnvNwaves <= 4 && groups % kEnvNwaves == 0 && p.nfrag == kNfrag) p.nwaves = kEnvNwaves;
     if (kEnvNfrag) {
         const int v = kEnvNfrag;
         if (v == 1 || v == 2) { p.nfrag = v; p.nwaves = 4; }
         if (v == 4) { p.nfrag = 4; p.nwaves = (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : (groups % 3 == 0) ? 3 : 1; }
     }
+    if (kEnvNwaves >= 1 && kEnvNwaves <= 4 && groups % kEnvNwaves == 0 && p.nfrag == kNfrag) p.nwaves = kEnvNwaves;
     return p;
 }
 

@@ -206,8 +206,12 @@ struct nsg_evaluator {
     hipStream_t chainStream[kMaxChains - 1] = {};
     hipEvent_t forkEvent = nullptr;
     hipEvent_t joinEvent[kMaxChains - 1] = {};
-    int numChains = 1;        // NSG_CHAINS (2 measured neutral, 4 slower: DESIGN.md)
-    int chainMinBatch = 512;  // NSG_CHAIN_MIN_BATCH
+    int numChains = 2;        // NSG_CHAINS (3 about equal, 4 slower: DESIGN.md 6)
+    int chainMinBatch = 0;    // NSG_CHAIN_MIN_BATCH; 0 = more 2-board tiles than CUs
+    nsg::ConvTuning tuning;   // NSG_CONV_* overrides, read at creation
+    nsg::ConvPlan lastPlan{0, 0, 0};
+    int lastChains = 0;
+    int chainDelayUs = 0;     // NSG_CHAIN_DELAY_US: start chain c that much later (x c)
 
     // profiling
     bool profile = false;
@@ -275,6 +279,12 @@ int uploadLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int
 
 int roundUp(int a, int b) { return (a + b - 1) / b * b; }
 
+// One wave that spins for `ticks` of the 100 MHz constant clock: phase-shifts a chain.
+__global__ void delayKernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // One chain = the whole forward for boards [off, off + count) on stream `s`.
 int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& plan, hipStream_t s,
                  bool stampsOk, hipEvent_t trunkBegin = nullptr, hipEvent_t trunkEnd = nullptr) {
@@ -328,7 +338,7 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     const int B = (int)n;
     hipStream_t s = ev->stream;
     // the tile plan is chosen for the whole batch: all chains run concurrently
-    const nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount);
+    const nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount, ev->tuning);
 
     const bool prof = ev->profile;
     if (prof && ev->evUsed + 4 > (int)ev->ev.size()) {
@@ -338,13 +348,17 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     hipEvent_t* e = prof ? &ev->ev[ev->evUsed] : nullptr;
     if (prof) NSG_HIP(hipEventRecord(e[0], s));
 
-    // Large batches run as independent chains of half-batch launches on separate
-    // streams: boards never interact, so chain A's layer l+1 may start while chain B
-    // is still in layer l.  Kernel-boundary tails and the epilogue's HBM bursts of one
-    // chain overlap the other chain's MFMA phase instead of idling the whole chip.
-    int chains = (B >= ev->chainMinBatch && plan.nb == 2) ? ev->numChains : 1;
+    // A batch with more tiles than CUs runs as two independent chains of half-batch
+    // launches on separate streams: boards never interact, so chain A's layer l+1 may
+    // start while chain B is still in layer l.  The partly filled last round of
+    // workgroups of one chain's launch is topped up by the other chain's launch instead
+    // of idling the chip (B=640: 82.7k -> 111.6k evals/s; B=1024: 113.8k -> 119.7k).
+    const int minBatch = ev->chainMinBatch > 0 ? ev->chainMinBatch : 2 * ev->prop.multiProcessorCount + 1;
+    int chains = (B >= minBatch && plan.nb == 2) ? ev->numChains : 1;
     if (ev->useTrunkKernel && nsg::canRunTrunk(ev->F, plan)) chains = 1;
     const int per = ((B + chains - 1) / chains + 1) / 2 * 2; // boards per chain, whole 2-board tiles
+    ev->lastPlan = plan;
+    ev->lastChains = chains;
 
     if (chains == 1 && ev->useTrunkKernel && nsg::canRunTrunk(ev->F, plan)) {
         // one persistent launch for all 2N+1 3x3 layers (measured slower; NSG_TRUNK_KERNEL=1)
@@ -374,6 +388,9 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
             if (count <= 0) break;
             hipStream_t cs = (c == 0) ? s : ev->chainStream[c - 1];
             if (c > 0) NSG_HIP(hipStreamWaitEvent(cs, ev->forkEvent, 0));
+            if (c > 0 && ev->chainDelayUs > 0) {
+                hipLaunchKernelGGL(delayKernel, dim3(1), dim3(64), 0, cs, (unsigned long long)ev->chainDelayUs * 100ull * c);
+            }
             int rc = enqueueChain(ev, off, count, plan, cs, c == 0);
             if (rc) return rc;
             if (c > 0) {
@@ -438,6 +455,8 @@ int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator**
         const int v = atoi(e2);
         if (v >= 1 && v <= nsg_evaluator::kMaxChains) ev->numChains = v;
     }
+    ev->tuning = nsg::readConvTuning();
+    if (const char* e2 = getenv("NSG_CHAIN_DELAY_US")) ev->chainDelayUs = std::max(0, atoi(e2));
     if (const char* e2 = getenv("NSG_CHAIN_MIN_BATCH")) ev->chainMinBatch = std::max(2, atoi(e2));
     *out = ev.release();
     return NSG_OK;
@@ -733,6 +752,15 @@ int nsg_profile_read(nsg_evaluator* ev, double* trunk_ms_total, uint64_t* trunk_
     if (forwards) *forwards = ev->forwards;
     ev->trunkMs = ev->fwdMs = 0;
     ev->trunkLaunches = ev->forwards = 0;
+    return NSG_OK;
+}
+
+int nsg_get_last_plan(nsg_evaluator* ev, int* nb, int* nfrag, int* nwaves, int* chains) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    if (nb) *nb = ev->lastPlan.nb;
+    if (nfrag) *nfrag = ev->lastPlan.nfrag;
+    if (nwaves) *nwaves = ev->lastPlan.nwaves;
+    if (chains) *chains = ev->lastChains;
     return NSG_OK;
 }
 

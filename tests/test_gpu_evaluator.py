@@ -197,10 +197,16 @@ def test_reduced_precision_paths(nsg, oracle, precision, tol):
     assert np.isfinite(out[0]).all()
 
 
-@pytest.mark.parametrize("env", [{"NSG_TRUNK_KERNEL": "1"}, {"NSG_CONV_NB": "1"}, {"NSG_CONV_NFRAG": "2"},
-                                 {"NSG_CONV_NFRAG": "1", "NSG_CONV_NB": "2"}])
+@pytest.mark.parametrize("env,expect", [
+    ({"NSG_TRUNK_KERNEL": "1"}, {}),
+    ({"NSG_CONV_NB": "1"}, {"boards_per_group": 1}),
+    ({"NSG_CONV_NFRAG": "2"}, {"fragments_per_wave": 2}),
+    ({"NSG_CONV_NFRAG": "1", "NSG_CONV_NB": "2"}, {"fragments_per_wave": 1, "boards_per_group": 2}),
+    ({"NSG_CONV_NFRAG": "4", "NSG_CONV_NB": "2", "NSG_CONV_NWAVES": "2"},
+     {"fragments_per_wave": 4, "boards_per_group": 2, "waves_per_group": 2}),
+])
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
-def test_alternative_launch_plans_agree(nsg, oracle, monkeypatch, env, precision):
+def test_alternative_launch_plans_agree(nsg, oracle, monkeypatch, env, expect, precision):
     """The tuning knobs (persistent one-launch trunk, tile shapes) change the launch
     plan, not the arithmetic: results stay within the oracle tolerance."""
     for k, v in env.items():
@@ -208,5 +214,32 @@ def test_alternative_launch_plans_agree(nsg, oracle, monkeypatch, env, precision
     ev, blob = make(nsg, 2, 256, 70, precision=precision, seed=31)
     bb = nsg.synth.random_batch(70, 86, seed=31)
     p, v, d = ev.compute_blocking(bb)
+    plan = ev.last_plan()
+    for k, want in expect.items():
+        assert plan[k] == want, (plan, env)
     idx = [0, 35, 69]
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), 2e-4)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_half_batch_chains_bit_identical(nsg, oracle, monkeypatch, precision):
+    """A batch with more 2-board tiles than CUs runs as two half-batch chains on two
+    streams (odd half sizes included); the split changes scheduling only, so outputs are
+    bit-identical to the single-chain run and match the oracle."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    batch = 2 * cus + 71
+    bb = nsg.synth.random_batch(batch, 86, seed=77)
+    ev, blob = make(nsg, 2, 256, batch, precision=precision, seed=32)
+    p, v, d = ev.compute_blocking(bb)
+    assert ev.last_plan()["chains"] == 2
+    monkeypatch.setenv("NSG_CHAINS", "1")
+    ev1, _ = make(nsg, 2, 256, batch, precision=precision, seed=32)
+    p1, v1, d1 = ev1.compute_blocking(bb)
+    assert ev1.last_plan()["chains"] == 1
+    np.testing.assert_array_equal(p, p1)
+    np.testing.assert_array_equal(v, v1)
+    np.testing.assert_array_equal(d, d1)
+    idx = [0, batch // 2 - 1, batch // 2, batch // 2 + 1, batch - 1]
     check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), 2e-4)
