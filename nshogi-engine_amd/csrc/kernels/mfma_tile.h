@@ -309,18 +309,25 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     // last slabs already request the next chunk's first row fragments -- no drain, no
     // LDS write latency and no cold fragment read between chunks.
     constexpr bool kFlow = (kSlabs >= 9);
-    // kF16x3 with a two-deep fragment ring: slabs (w_hi,x_hi) and (w_lo,x_hi) of a tap
-    // share their row fragments, so a tap needs two fragment loads (hi -> a[0] during the
-    // previous tap's last slab, lo -> a[1] during this tap's first slab), not three.
-    constexpr bool kSlot = kFlow && kSplit && (kRingA == 2);
+    // kF16x3: slabs (w_hi,x_hi) and (w_lo,x_hi) of a tap share their row fragments, so a
+    // tap needs two fragment sets (hi, lo), not three.  Set u = 2*tap + (lo ? 1 : 0)
+    // lives in a[u % kSlotR]:
+    //   two sets (full tiles):  lo_t is requested during slab (t,0), hi_t+1 during (t,2);
+    //   three sets (small tiles): hi_t+1 during (t,0), lo_t+1 during (t,2) -- three slabs
+    //   of lead, which a slab of only 6 or 12 MFMAs needs to cover the LDS latency.
+    constexpr int kSlotR = (kFlow && kSplit) ? kRingA : 0;
+    constexpr bool kSlot = kSlotR > 0;
     static_assert(!kFlow || kSlot || kSlabs % kRingA == 0, "ring slot must carry across chunks");
+    static_assert(!kSlot || (2 * G::kTaps) % kSlotR == 0, "fragment sets must carry across chunks");
     constexpr int kWriteSlab = kSlot ? 3 * (G::kTaps / 3) + 1 : kSlabs / 3;
-    constexpr int kBarSlab = kSlot ? kSlabs - 2 : kSlabs - kRingA + 1; // barrier at the top of this slab
+    // barrier at the top of the first slab that reads the next chunk's buffer
+    constexpr int kBarSlab = kSlot ? (kSlotR == 2 ? kSlabs - 1 : kSlabs - 3) : kSlabs - kRingA + 1;
     if constexpr (kFlow) {
 #pragma unroll
-        for (int q = 0; q < (kSlot ? 1 : kRingA - 1); ++q)
+        for (int q = 0; q < (kSlot ? kSlotR - 1 : kRingA - 1); ++q)
 #pragma unroll
-            for (int f = 0; f < G::kMF; ++f) a[q][f] = *reinterpret_cast<const u32x4*>(smem + abase[f] + slabOff(q));
+            for (int f = 0; f < G::kMF; ++f)
+                a[q][f] = *reinterpret_cast<const u32x4*>(smem + abase[f] + slabOff(kSlot ? 2 * q : q));
     }
     for (int kc = 0; kc < nkc; ++kc) {
         const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
@@ -344,19 +351,18 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             // -- requests for later slabs
             bool dsReads = true;
             if constexpr (kSlot) {
-                const int r = s % 3;
+                const int r = s % 3, t = s / 3;
                 dsReads = (r != 1);
-                if (r == 0) { // this tap's lo fragments
-                    const int off1 = slabOff(s + 2);
+                // which set to request: (tap, lo?) and where it goes
+                const int nt = (kSlotR == 2) ? (r == 0 ? t : t + 1) : t + 1;
+                const bool nlo = (kSlotR == 2) ? (r == 0) : (r == 2);
+                if (r != 1) {
+                    const unsigned char* src = (nt < G::kTaps) ? abuf : nbuf;
+                    const int off1 = slabOff(3 * (nt % G::kTaps) + (nlo ? 2 : 0));
 #pragma unroll
                     for (int f = 0; f < G::kMF; ++f)
-                        a[1][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + off1);
-                } else if (r == 2) { // next tap's hi fragments (after the last tap: next chunk's)
-                    const unsigned char* src = (s + 1 < kSlabs) ? abuf : nbuf;
-                    const int off1 = slabOff((s + 1) % kSlabs);
-#pragma unroll
-                    for (int f = 0; f < G::kMF; ++f)
-                        a[0][f] = *reinterpret_cast<const u32x4*>(src + abase[f] + off1);
+                        a[(2 * nt + (nlo ? 1 : 0)) % kSlotR][f] =
+                            *reinterpret_cast<const u32x4*>(src + abase[f] + off1);
                 }
             } else if (s + kRingA - 1 < kSlabs) {
                 const int off1 = slabOff(s + kRingA - 1);
@@ -375,7 +381,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 for (int j = 0; j < NFRAG; ++j) w[(s + kRing - 1) % kRing][j] = wp[j * 64];
             }
             // -- this slab's MFMAs
-            const int aslot = kSlot ? (s % 3 == 2 ? 1 : 0) : s % kRingA;
+            const int aslot = kSlot ? (2 * (s / 3) + (s % 3 == 2 ? 1 : 0)) % kSlotR : s % kRingA;
 #pragma unroll
             for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
