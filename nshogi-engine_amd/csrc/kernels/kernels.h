@@ -27,6 +27,9 @@ inline int chunkChannels(int prec) { return 128 / elemSize(prec); }
 // MFMA K-slabs per (chunk, tap): two halves of the chunk, or for kF16x3 the three
 // products (w_hi,x_hi) (w_lo,x_hi) (w_hi,x_lo) over the chunk's 32 channels.
 inline int slabsPerTap(int prec) { return prec == kF16x3 ? 3 : 2; }
+// Packed weight records per (chunk, tap): the two K halves, or for kF16x3 (w_hi, w_lo)
+// -- w_hi serves both of its products from registers.
+inline int recordsPerTap(int) { return 2; }
 
 // ---- feature-plane expansion (reference K1/K2, src/cuda/extractbit.cu) ----
 hipError_t launchExtractBitsNCHW(float* dst, const uint64_t* src, int batch,

@@ -252,9 +252,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             st[k];                                                                       \
     }
 
-    // weight stream: slab q = (kc*taps + tap)*2 + s, NFRAG 1-KiB records per wave,
-    // held in a register ring kRing slabs deep (slab q+kRing-1 is requested while slab
-    // q computes, so a weight load has whole slabs of MFMAs to cover its L2 latency).
+    // weight stream: record q = (kc*taps + tap)*2 + s, NFRAG 1-KiB records per wave, held
+    // in a register ring (a record is requested whole slabs of MFMAs before its first use,
+    // which is what covers the L2 latency).  16-bit / f32: one record per slab.  kF16x3: two
+    // records per tap (w_hi, w_lo) for three slabs -- w_hi stays in registers for its
+    // second product instead of being streamed twice.
     constexpr int kSlabsPerTap = kSplit ? 3 : 2;
     constexpr int kSlabs = kSlabsPerTap * G::kTaps;    // slabs per channel chunk
     // LDS byte offset of slab s's row fragments inside the chunk image: tap shift +
@@ -270,17 +272,26 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     // round trip with one slab of lead; a small-batch tile has as few as 6 MFMAs per
     // slab, so its weight ring runs 8 slabs ahead and its row fragments 2 slabs ahead.
     constexpr bool kDeep = (NFRAG <= 2) && (kSlabs % 9 == 0);
-    constexpr int kRing = kDeep ? 9 : ((kSlabs % 3 == 0) ? 3 : 2);   // weight records
+    constexpr int kRing = kDeep ? 9 : ((kSlabs % 3 == 0) ? 3 : 2);   // weight records (non-split)
     constexpr int kRingA = (kDeep || (NFRAG <= 2 && kSlabs % 3 == 0)) ? 3 : 2; // row fragments
     constexpr int kMfmaPerPair = (PREC == kFp32) ? 4 : 1;
+    // kF16x3 weight registers.  kWMode 1 (full tiles): three sets -- w_lo in set 1, w_hi
+    // alternating between sets 0 and 2 tap by tap; hi_t+1 is requested during slab (t,0)
+    // and lo_t+1 during (t,2) (three and two slabs of lead).  With an odd number of taps
+    // per chunk the next chunk's hi_0 lands in set 2 and is moved to set 0 at the chunk
+    // boundary.  kWMode 2 (small tiles): kWR records, record u in set u % kWR, requested
+    // kWR/2 - 1 taps ahead (a one-fragment wave has 6 MFMAs per slab to hide a load behind).
+    constexpr int kWMode = !kSplit ? 0 : (kDeep ? 2 : 1);
+    constexpr int kWR = (NFRAG == 1) ? 18 : 6;
+    constexpr int kWSets = kWMode == 0 ? kRing : (kWMode == 1 ? 3 : kWR);
     const size_t slabStride = (size_t)nft * 64;
     const u32x4* wp = A.w + (size_t)waveGroup * NFRAG * 64 + lane;
-    u32x4 w[kRing][NFRAG];
-    constexpr int kLead = (kRing == 2) ? 2 : kRing - 1; // slabs requested ahead of use
+    u32x4 w[kWSets][NFRAG];
+    constexpr int kLead = kWMode == 0 ? ((kRing == 2) ? 2 : kRing - 1) : (kWMode == 1 ? 2 : kWR - 2); // records requested up front
 #pragma unroll
     for (int q = 0; q < kLead; ++q)
 #pragma unroll
-        for (int j = 0; j < NFRAG; ++j) w[q % kRing][j] = wp[(size_t)q * slabStride + j * 64];
+        for (int j = 0; j < NFRAG; ++j) w[q % kWSets][j] = wp[(size_t)q * slabStride + j * 64];
     wp += (size_t)kLead * slabStride;
 
     f32x4 acc[G::kMF][NFRAG];
@@ -376,33 +387,62 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 for (int f = 0; f < G::kMF; ++f)
                     a[(s + kRingA - 1) % kRingA][f] = *reinterpret_cast<const u32x4*>(nbuf + abase[f] + off1);
             }
-            if constexpr (kRing >= 3) {
+            // -- weight records for later slabs, and which set this slab multiplies by
+            int wset = s % kRing;
+            bool wLoads = true;
+            if constexpr (kWMode == 0) {
+                if constexpr (kRing >= 3) {
 #pragma unroll
-                for (int j = 0; j < NFRAG; ++j) w[(s + kRing - 1) % kRing][j] = wp[j * 64];
+                    for (int j = 0; j < NFRAG; ++j) w[(s + kRing - 1) % kRing][j] = wp[j * 64];
+                }
+            } else {
+                const int r = s % 3, t = s / 3;
+                int dst = -1;
+                if constexpr (kWMode == 1) {
+                    wset = (r == 1) ? 1 : (t & 1) * 2;
+                    if (r == 0) dst = ((t + 1) & 1) * 2; // hi of the next tap
+                    if (r == 2) dst = 1;                 // lo of the next tap
+                } else {
+                    wset = (2 * t + (r == 1 ? 1 : 0)) % kWR;
+                    if (r == 0) dst = (2 * t + kWR - 2) % kWR;   // hi, kWR/2 - 1 taps ahead
+                    if (r == 1) dst = (2 * t + kWR - 1) % kWR;   // lo
+                }
+                wLoads = dst >= 0;
+                if (dst >= 0) {
+#pragma unroll
+                    for (int j = 0; j < NFRAG; ++j) w[dst][j] = wp[j * 64];
+                    wp += slabStride;
+                }
             }
             // -- this slab's MFMAs
             const int aslot = kSlot ? (2 * (s / 3) + (s % 3 == 2 ? 1 : 0)) % kSlotR : s % kRingA;
 #pragma unroll
             for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w[s % kRing][j], a[aslot][f]);
-            if constexpr (kRing == 2) {
+                for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w[wset][j], a[aslot][f]);
+            if constexpr (kWMode == 0) {
+                if constexpr (kRing == 2) {
 #pragma unroll
-                for (int j = 0; j < NFRAG; ++j) w[s % 2][j] = wp[j * 64];
+                    for (int j = 0; j < NFRAG; ++j) w[s % 2][j] = wp[j * 64];
+                }
+                wp += slabStride;
             }
-            wp += slabStride;
             if constexpr (kRing >= 3) {
                 // interleave: one LDS read (+ one weight load) per NFRAG row-fragment MFMAs
 #pragma unroll
                 for (int f = 0; f < G::kMF; ++f) {
                     if (dsReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
-                    if (f < NFRAG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
+                    if (wLoads && f < NFRAG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
                     if (kFlow && s == kWriteSlab && f < G::kItems)
                         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); // DS write
                     __builtin_amdgcn_sched_group_barrier(0x008, NFRAG * kMfmaPerPair, 0); // MFMA
                 }
             }
             __builtin_amdgcn_sched_barrier(0); // nothing sinks out of its slab
+        }
+        if constexpr (kWMode == 1 && (G::kTaps & 1)) {
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j) w[0][j] = w[2][j]; // next chunk's hi_0
         }
         if constexpr (!kFlow) {
             NSG_STAGE_WRITE((kc + 1) & 1)

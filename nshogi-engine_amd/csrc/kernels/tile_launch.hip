@@ -216,11 +216,11 @@ hipError_t launchValueOut(const float* h, const float* w2, const float* b2,
 // Host-side weight packing.  Record (q, nf, lane) holds, for MFMA row
 // rho = lane & 15 and lane group g = lane >> 4 of output fragment nf:
 //   out channel n = (nf / 4) * 64 + (rho >> 2) * 16 + (nf % 4) * 4 + (rho & 3)
-//   slab        q = (kc*taps + tap)*slabsPerTap + s
+//   record      q = (kc*taps + tap)*2 + s
 //   f32  : 4 values, input channel kc*32 + s*16 + 4*g + i          (i = 0..3)
 //   16b  : 8 values, input channel kc*64 + s*32 + 8*g + i          (i = 0..7)
-//   f16x3: 8 values, input channel kc*32 + 8*g + i; s = 0: hi, 1: lo, 2: hi
-// Eight zero slabs are appended so the kernel's prefetch (up to 8 slabs ahead for
+//   f16x3: 8 values, input channel kc*32 + 8*g + i; s = 0: hi, 1: lo
+// Sixteen zero records are appended so the kernel's prefetch (up to 16 records ahead for
 // small-batch tiles) never reads past the allocation.
 // ---------------------------------------------------------------------------
 static inline uint16_t hostF32ToF16(float f) {
@@ -239,7 +239,7 @@ static inline uint16_t hostF32ToBf16(float f) {
 
 size_t tileWeightRecords(int taps, int kdim, int cout, int prec) {
     const int nkc = kdim / chunkChannels(prec);
-    return ((size_t)nkc * taps * slabsPerTap(prec) + 8) * (cout / 16) * 64; // + 8 zero slabs: deepest prefetch
+    return ((size_t)nkc * taps * recordsPerTap(prec) + 16) * (cout / 16) * 64; // + 16 zero records: deepest prefetch
 }
 
 void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
@@ -247,7 +247,7 @@ void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
     const int kcCh = chunkChannels(prec);
     const int nkc = kdim / kcCh;
     const int nft = cout / 16;
-    const int spt = slabsPerTap(prec);
+    const int spt = recordsPerTap(prec);
     const int per = (prec == kFp32) ? 4 : 8; // values per record
     unsigned char* out = (unsigned char*)dst;
     memset(out, 0, tileWeightRecords(taps, kdim, cout, prec) * 16);
@@ -262,14 +262,14 @@ void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
                                       (nf % kNfrag) * 4 + (rho & 3);
                         unsigned char* rec = out + ((q * nft + nf) * 64 + lane) * 16;
                         for (int i = 0; i < per; ++i) {
-                            // kF16x3: all three slabs cover the chunk's 32 channels
+                            // kF16x3: both records cover the chunk's 32 channels
                             const int k = (prec == kF16x3) ? c * kcCh + per * g + i
                                                            : c * kcCh + s * (kcCh / 2) + per * g + i;
                             const float v = (k < kReal) ? get(ctx, n, k, t) * scale : 0.f;
                             if (prec == kFp32) {
                                 memcpy(rec + i * 4, &v, 4);
                             } else if (prec == kF16x3) {
-                                // slabs: (w_hi, x_hi) (w_lo, x_hi) (w_hi, x_lo)
+                                // records: w_hi (products with x_hi and x_lo), w_lo (with x_hi)
                                 const _Float16 h = (_Float16)v;
                                 const _Float16 l = (_Float16)(v - (float)h);
                                 const _Float16 pick = (s == 1) ? l : h;
