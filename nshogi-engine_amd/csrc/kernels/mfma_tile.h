@@ -25,13 +25,12 @@
 //   Rows are 10 entries wide: the single zero entry x=9 is both the right
 //   halo of row y and the left halo of row y+1; rows y=-1 and y=9 are zero
 //   halo rows.  A tap is therefore a constant entry offset dy*10+dx with no
-//   bounds test, and because one chunk plane is a multiple of 256 B the
-//   ds_read_b128 of 16 consecutive entries is bank-conflict free.
+//   bounds test.
 // * Every wave owns ALL rows of the tile and NFRAG*16 output channels, so
 //   activation fragments are shared through LDS while weight fragments are
 //   private to a wave: they stream straight from L2 into registers as 1-KiB
 //   fully coalesced wave loads (the host pre-packs them in lane order), two
-//   K-slabs ahead of use.
+//   to three K-slabs ahead of use.
 // * The MFMA takes the weights as its A operand and the rows as its B
 //   operand, so a lane ends up holding 4 consecutive output channels of one
 //   row; the channel<->MFMA-row map is chosen at pack time so that a lane's
