@@ -32,8 +32,12 @@ if ROOT not in sys.path:
 # Default precision f16x3: the fastest path that meets the north_star's 1e-3 parity
 # (measured 5e-6 vs the CPU oracle, like the exact-f32 path; plain f16 / bf16 do not).
 # MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2516.6, "bf16": 2516.6, "f16x3": 2516.6}
-DTYPE_NAME = {"fp32": "f32", "fp16": "f16", "bf16": "bf16", "f16x3": "f16x3 (split f16 hi/lo, f32 accumulate)"}
+PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2516.6, "bf16": 2516.6, "f16x3": 2516.6, "f16m8": 2516.6}
+DTYPE_NAME = {"fp32": "f32", "fp16": "f16", "bf16": "bf16", "f16x3": "f16x3 (split f16 hi/lo, f32 accumulate)",
+              "f16m8": "f16m8 (f16 main term + fp8 MX correction terms, f32 accumulate)"}
+# matrix-pipe work per algorithmic MAC in units of one f16 MFMA MAC (the MX instruction
+# retires 4x the K of the f16 one in 2x its cycles; 9 f16 + 5 MX slabs per 9 taps)
+MFMA_UNITS = {"fp32": 1, "fp16": 1, "bf16": 1, "f16x3": 3, "f16m8": (9 + 5 * 2) / 9}
 
 
 def cpu_baseline(seconds=12.0):
@@ -107,7 +111,7 @@ def selfplay_leg(weights_path, gpu, seconds, threads, precision, playouts=800, g
     the reference's option names/values of config 4 (--num-playouts 800, batch = games per
     group).  games/sec = finished games / elapsed (saveworker.cc:135-137)."""
     import subprocess
-    prec = {"fp32": 0, "fp16": 1, "bf16": 2, "f16x3": 3}[precision]
+    prec = {"fp32": 0, "fp16": 1, "bf16": 2, "f16x3": 3, "f16m8": 4}[precision]
     r = subprocess.run([SELFPLAY_BIN, "--executor", "hip", "--weights", weights_path, "--gpu", str(gpu),
                         "--threads", str(threads), "--games-per-group", str(games_per_group),
                         "--playouts", str(playouts), "--seconds", str(seconds), "--seed", "1",
@@ -134,7 +138,7 @@ def main():
     ap.add_argument("--net", default="20x256", help="blocks x channels, e.g. 10x192, 20x256, 40x384")
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--precision", default=os.environ.get("NSG_BENCH_PRECISION", "f16x3"),
-                    choices=["fp32", "fp16", "bf16", "f16x3"])
+                    choices=["fp32", "fp16", "bf16", "f16x3", "f16m8"])
     ap.add_argument("--selfplay-seconds", type=float, default=30.0,
                     help="length of the self-play leg (metric #2, games/sec); 0 disables it")
     # BASELINE configs[3]: 256 concurrent games per GPU = 2 threads x 2 groups x 64 games
@@ -258,7 +262,7 @@ def main():
                        "weights": "synthetic He-normal seed 0, BN folded, broadcast from rank 0"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": conv_traffic_bytes(args, B),
-                         "mfma_flops_executed_per_algorithmic_flop": 3 if args.precision == "f16x3" else 1,
+                         "mfma_flops_executed_per_algorithmic_flop": MFMA_UNITS[args.precision],
                          "kernel": "tileKernel<kConv> (3x3 conv F->F, bias+residual+ReLU fused)",
                          "avg_launch_ms": conv_ms, "launches_timed": prof["trunk_launches"],
                          "algorithmic_flops_per_launch": conv_flops_launch},
@@ -285,7 +289,7 @@ def main():
             out["host_path_evals_per_sec"] = B * reps / (time.perf_counter() - t1)
         if not args.no_host_path and world == 1:
             out["other_precisions_evals_per_sec"] = {
-                p: quick_rate(nsg, local_rank, blob, bb, B, p) for p in ("fp32", "f16x3", "fp16", "bf16")
+                p: quick_rate(nsg, local_rank, blob, bb, B, p) for p in ("fp32", "f16x3", "f16m8", "fp16", "bf16")
                 if p != args.precision}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

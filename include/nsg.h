@@ -51,6 +51,12 @@ extern "C" {
  * pairs, products evaluated as hi*hi + lo*hi + hi*lo with f32 accumulation
  * (~22 significant bits). */
 #define NSG_PRECISION_F16X3 3
+/* F16X3 with the two correction products (each 2^-11 of the result) evaluated on
+ * fp8 copies of the operands by the MX matrix instruction
+ * (v_mfma_scale_f32_16x16x128_f8f6f4): 2.1 instead of 3 MFMA units per MAC,
+ * ~2e-4 from the CPU fp32 executor on the 20x256 net (F16X3: 5e-6).  Trunk
+ * convolutions only; the heads and the value MLP run as F16X3. */
+#define NSG_PRECISION_F16M8 4
 
 typedef struct nsg_evaluator nsg_evaluator;
 

@@ -18,7 +18,7 @@ MOVE_INDEX_MAX = 2187
 NUM_SQUARES = 81
 BITBOARD_BYTES = 16
 
-_PREC_NAMES = {"fp32": 0, "f32": 0, "fp16": 1, "f16": 1, "bf16": 2, "f16x3": 3}
+_PREC_NAMES = {"fp32": 0, "f32": 0, "fp16": 1, "f16": 1, "bf16": 2, "f16x3": 3, "f16m8": 4}
 
 
 class NsgError(RuntimeError):

@@ -162,6 +162,27 @@ __global__ __launch_bounds__(kThreads) void extractAct(
             }
             *reinterpret_cast<uint2*>(row) = make_uint2(hb[0] | ((uint32_t)hb[1] << 16), hb[2] | ((uint32_t)hb[3] << 16));
             *reinterpret_cast<uint2*>(row + 64) = make_uint2(lb[0] | ((uint32_t)lb[1] << 16), lb[2] | ((uint32_t)lb[3] << 16));
+        } else if constexpr (PREC == kF16m8) {
+            // row = 128-byte chunks of 32 channels: [32 x f16 hi][32 x e4m3(hi)][32 x e4m3(lo * 2^12)]
+            unsigned char* row = (unsigned char*)dstv + ((size_t)b * 81 + sq) * cpad * 4 +
+                                 (size_t)(c0 >> 5) * 128;
+            uint16_t hb[4];
+            float hf[4], lf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = fminf(fmaxf(__uint_as_float(vv[i]), -65000.f), 65000.f);
+                const _Float16 h = (_Float16)v;
+                hb[i] = __builtin_bit_cast(uint16_t, h);
+                hf[i] = __builtin_amdgcn_fmed3f((float)h, -448.f, 448.f);
+                lf[i] = __builtin_amdgcn_fmed3f((v - (float)h) * (float)(1 << kM8LoShift), -448.f, 448.f);
+            }
+            int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[0], hf[1], 0, false);
+            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[2], hf[3], h8, true);
+            int l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[0], lf[1], 0, false);
+            l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[2], lf[3], l8, true);
+            *reinterpret_cast<uint2*>(row + (c0 & 31) * 2) = make_uint2(hb[0] | ((uint32_t)hb[1] << 16), hb[2] | ((uint32_t)hb[3] << 16));
+            *reinterpret_cast<uint32_t*>(row + 64 + (c0 & 31)) = (uint32_t)h8;
+            *reinterpret_cast<uint32_t*>(row + 96 + (c0 & 31)) = (uint32_t)l8;
         } else if constexpr (PREC == kFp32) {
             *reinterpret_cast<uint4*>((uint32_t*)dstv + e) =
                 make_uint4(v[0], v[1], v[2], v[3]);
@@ -238,6 +259,9 @@ hipError_t launchExtractBitsAct(void* dst, const uint64_t* src, int batch,
                            stream, dst, (const uint4*)src, channels, cpad);
     } else if (prec == kF16x3) {
         hipLaunchKernelGGL(extractAct<kF16x3>, dim3(batch), dim3(kThreads), smem,
+                           stream, dst, (const uint4*)src, channels, cpad);
+    } else if (prec == kF16m8) {
+        hipLaunchKernelGGL(extractAct<kF16m8>, dim3(batch), dim3(kThreads), smem,
                            stream, dst, (const uint4*)src, channels, cpad);
     } else {
         hipLaunchKernelGGL(extractAct<kBf16>, dim3(batch), dim3(kThreads), smem,

@@ -18,10 +18,24 @@ namespace nsg {
 // lo = f16(v - hi), and every product is evaluated as hi*hi + lo*hi + hi*lo on the
 // f16 MFMA with f32 accumulation: ~22 significant bits (f32 has 24) at three
 // 16-bit MFMAs per MAC instead of sixteen f32-MFMA cycles' worth.
-enum Precision { kFp32 = 0, kFp16 = 1, kBf16 = 2, kF16x3 = 3 };
+//
+// kF16m8 (trunk convolutions only): the main term w_hi*x_hi stays on the f16 MFMA, the
+// two correction terms w_lo*x_hi and w_hi*x_lo -- each 2^-11 of the product -- are
+// evaluated on fp8 (e4m3) copies of the operands by v_mfma_scale_f32_16x16x128_f8f6f4,
+// which retires four times the K of the f16 instruction in twice its cycles: 2.1 instead
+// of 3 MFMA units per MAC.  Activations: 128-byte chunks of 32 channels,
+// [32 x f16 hi][32 x e4m3(hi)][32 x e4m3(lo * 2^12)].  The 1x1 heads and the value MLP of
+// a kF16m8 evaluator run as kF16x3 (the last trunk layer writes the kF16x3 layout).
+enum Precision { kFp32 = 0, kFp16 = 1, kBf16 = 2, kF16x3 = 3, kF16m8 = 4 };
+constexpr int kM8LoShift = 12;   // stored lo byte = e4m3(lo * 2^12)
+constexpr int kM8WLoShift = 10;  // weight record  = e4m3(w_lo * 2^10)
+constexpr int kM8WHiShift = -2;  // weight record  = e4m3(w_hi * 2^-2); both products carry 2^-10
+constexpr int kM8ScaleByte = 127 - 10; // E8M0 block scale of the weight operand
 
-// Bytes one activation channel occupies (a kF16x3 pair is 2 + 2 bytes).
-inline int elemSize(int prec) { return (prec == kFp32 || prec == kF16x3) ? 4 : 2; }
+// Bytes one activation channel occupies (a kF16x3 pair is 2 + 2 bytes, kF16m8 2 + 1 + 1).
+inline int elemSize(int prec) { return (prec == kFp32 || prec == kF16x3 || prec == kF16m8) ? 4 : 2; }
+// Precision of the 1x1 heads / value MLP of an evaluator whose trunk runs at `prec`.
+inline int headPrecision(int prec) { return prec == kF16m8 ? (int)kF16x3 : prec; }
 // Channels per 128-byte K chunk of the trunk convolution.
 inline int chunkChannels(int prec) { return 128 / elemSize(prec); }
 // MFMA K-slabs per (chunk, tap): two halves of the chunk, or for kF16x3 the three
@@ -30,6 +44,12 @@ inline int slabsPerTap(int prec) { return prec == kF16x3 ? 3 : 2; }
 // Packed weight records per (chunk, tap): the two K halves, or for kF16x3 (w_hi, w_lo)
 // -- w_hi serves both of its products from registers.
 inline int recordsPerTap(int) { return 2; }
+// 1-KiB-per-fragment weight records per channel chunk.  kF16m8: one f16 record per tap
+// (w_hi) plus, per pair of taps, two records holding the 32 fp8 bytes per lane of the MX
+// operand (k-group g: tap 2p + (g>>1), g&1 ? e4m3(w_hi) : e4m3(w_lo)).
+inline int recordsPerChunk(int taps, int prec) {
+    return prec == kF16m8 ? taps + 2 * ((taps + 1) / 2) : taps * recordsPerTap(prec);
+}
 
 // ---- feature-plane expansion (reference K1/K2, src/cuda/extractbit.cu) ----
 hipError_t launchExtractBitsNCHW(float* dst, const uint64_t* src, int batch,
@@ -54,6 +74,7 @@ constexpr int kNfrag = 4; // every packed tensor uses 4 fragments (64 channels) 
 // evaluator is created.
 struct ConvTuning {
     int nb = 0, nwaves = 0, nfrag = 0;
+    bool fullTilesOnly = false; // kF16m8: 4 fragments per wave at every batch size
 };
 ConvTuning readConvTuning();
 
@@ -68,7 +89,7 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
                          const void* residual, void* y, int batch, int cin,
                          int cout, int relu, float accScale, int prec,
                          const ConvPlan& plan, hipStream_t stream,
-                         unsigned long long* stamps = nullptr);
+                         unsigned long long* stamps = nullptr, bool outF16x3 = false);
 
 // Persistent trunk: every 3x3 layer (stem + 2 per block) in ONE launch.  A layer
 // list is built once with trunkLayersBytes()/fillTrunkLayer() on the host, uploaded,

@@ -160,6 +160,7 @@ struct Args {
     int valueChannels;        // kHeads: channels [0,VC) = value conv, [VC,VC+27) = policy
     int vfeatStride;          // kHeads: elements per board row of vfeat (>= 81*VC)
     float accScale;           // accumulators are multiplied by this before the bias (kF16x3: 1/weight scale)
+    int outF16x3;             // kF16m8: write the kF16x3 layout (last trunk layer, read by the heads)
     unsigned long long* stamps; // diagnostic builds only (NSG_DIAG_STAMPS): 8 u64 per workgroup
 };
 
@@ -184,6 +185,27 @@ constexpr int minWavesPerSimd() {
     return (MODE == kConv && SIZE == 1 && (NWAVES >= 3 || NFRAG <= 2)) ? 2 : 1;
 }
 
+// kF16m8 slab sequence of one channel chunk: m0 m1 X0 m2 m3 X1 ... (m_t: f16 main term of
+// tap t; X_p: fp8 correction terms of taps 2p, 2p+1 on the K=128 MX instruction).
+template <int TAPS>
+struct M8Seq {
+    static constexpr int kNX = (TAPS + 1) / 2;
+    static constexpr int kSlabs = TAPS + kNX;
+    static constexpr int kFull = 3 * (TAPS / 2);
+    static constexpr bool isX(int s) { return s < kFull ? (s % 3 == 2) : (s == kFull + 1); }
+    static constexpr int tap(int s) { return s < kFull ? 2 * (s / 3) + (s % 3) : TAPS - 1; } // main slabs
+    static constexpr int pair(int s) { return s < kFull ? s / 3 : TAPS / 2; }                // X slabs
+    static constexpr int slabOfTap(int t) { return 3 * (t / 2) + (t & 1); }
+    static constexpr int slabOfPair(int p) { return p < TAPS / 2 ? 3 * p + 2 : kFull + 1; }
+    // record sets (nft x 1 KiB) before slab s: one per main slab, two per X slab
+    static constexpr int recOff(int s) { // closed form: s + (X slabs among the first s)
+        return s + (s <= kFull ? s / 3 : kFull / 3 + (s > kFull + 1 ? 1 : 0));
+    }
+    static constexpr int kRecChunk = TAPS + 2 * kNX;
+};
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
 // One layer's work for this workgroup.  RES: 0 = no residual, 1 = residual,
 // 2 = decided at run time by A.res (persistent trunk kernel).
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES>
@@ -191,8 +213,10 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     using G = Geom<MODE, SIZE, NWAVES>;
     const bool hasRes = (RES == 1) || (RES == 2 && A.res != nullptr);
     NSG_STAMP(0);
-    constexpr int ES = (PREC == kFp32 || PREC == kF16x3) ? 4 : 2;
+    constexpr bool kM8 = (PREC == kF16m8);
+    constexpr int ES = (PREC == kFp32 || PREC == kF16x3 || kM8) ? 4 : 2;
     constexpr bool kSplit = (PREC == kF16x3);
+    static_assert(!kM8 || (MODE == kConv && NFRAG == 4), "kF16m8: full trunk-conv tiles only");
     static_assert(NFRAG == 1 || NFRAG == 2 || NFRAG == 4, "fragments per wave");
 
     const int tid = threadIdx.x;
@@ -251,6 +275,134 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             st[k];                                                                       \
     }
 
+    f32x4 acc[G::kMF][NFRAG];
+#pragma unroll
+    for (int f = 0; f < G::kMF; ++f)
+#pragma unroll
+        for (int j = 0; j < NFRAG; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (kM8) {
+        // ---- kF16m8 main loop: per chunk the slab sequence m0 m1 X0 m2 m3 X1 ... m8 X4 as one
+        // continuous stream of steps (slab, row fragment).  Row fragments live in a rolling
+        // window of kWin register slots and are requested kD steps ahead (a step is 4 MFMAs:
+        // 64 clk for an f16 slab, 128 clk for an MX slab), across slab and chunk boundaries;
+        // the f16 weight records sit in three register sets (requested two main slabs
+        // ahead), the MX records in one (requested as soon as the previous MX slab is done).
+        using Q = M8Seq<G::kTaps>;
+        static_assert(G::kTaps % 3 == 0, "three f16 weight sets must carry across chunks");
+        constexpr int kSteps = Q::kSlabs * G::kMF;
+        constexpr int kWin = 7, kD = 5;
+        static_assert(kSteps % kWin == 0, "window slot must carry across chunks");
+        constexpr int kWriteStep = 4 * G::kMF;      // next chunk's tile -> LDS
+        constexpr int kBarStep = kSteps - kD;       // first step that requests next-chunk fragments
+        auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
+        // MX operand of lane (li, g): 32 fp8 bytes of tap 2p + (g>>1); g&1 ? lo bytes : hi bytes
+        int offp8[Q::kNX];
+#pragma unroll
+        for (int p = 0; p < Q::kNX; ++p) {
+            const int t0 = 2 * p, t1 = (2 * p + 1 < G::kTaps) ? 2 * p + 1 : 2 * p; // (missing tap: its weights are zero)
+            offp8[p] = (4 + 2 * (g & 1) - g) * G::kPlane + ((g >> 1) ? tapOff(t1) : tapOff(t0));
+        }
+        const size_t rs = (size_t)nft * 64; // one record set
+        const u32x4* wc = A.w + lane;
+        const size_t wg4 = (size_t)waveGroup * NFRAG * 64;  // this wave's records inside a main set
+        const size_t wg8 = wg4 * 2;                         //                          an MX pair of sets
+        u32x4 w4[3][NFRAG];
+        u32x4 w8[NFRAG][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j) w4[t][j] = wc[Q::recOff(Q::slabOfTap(t)) * rs + wg4 + j * 64];
+
+        NSG_STAGE_LOAD(0)
+        if (zeroLds) {
+            for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
+                reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        __syncthreads(); // zero fill done before staging writes
+        NSG_STAGE_WRITE(0)
+        __syncthreads();
+        NSG_STAMP(1);
+
+        u32x4 aw[kWin][2];
+        // fragment request of step q (q >= kSteps: the next chunk's step q - kSteps)
+#define NSG_M8_REQ(QQ, CUR, NXT)                                                                  \
+        {                                                                                         \
+            const int q_ = (QQ) % kSteps;                                                         \
+            const unsigned char* b_ = ((QQ) >= kSteps) ? (NXT) : (CUR);                           \
+            const int s_ = q_ / G::kMF, f_ = q_ % G::kMF;                                         \
+            if (Q::isX(s_)) {                                                                     \
+                const unsigned char* ap_ = b_ + abase[f_] + offp8[Q::pair(s_)];                   \
+                aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(ap_);                        \
+                aw[(QQ) % kWin][1] = *reinterpret_cast<const u32x4*>(ap_ + G::kPlane);            \
+            } else {                                                                              \
+                aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(b_ + abase[f_] + tapOff(Q::tap(s_))); \
+            }                                                                                     \
+        }
+#pragma unroll
+        for (int q = 0; q < kD; ++q) NSG_M8_REQ(q, smem, smem)
+
+        for (int kc = 0; kc < nkc; ++kc) {
+            const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
+            const unsigned char* nbuf = smem + ((kc + 1) & 1) * G::kBuf;
+            NSG_STAGE_LOAD(kc + 1 < nkc ? kc + 1 : kc)
+#pragma unroll
+            for (int s = 0; s < Q::kSlabs; ++s) {
+#pragma unroll
+                for (int f = 0; f < G::kMF; ++f) {
+                    const int q = s * G::kMF + f;
+                    if (q == kWriteStep) { NSG_STAGE_WRITE((kc + 1) & 1) }
+                    if (q == kBarStep) __syncthreads();
+                    const bool prevX = Q::isX((s + Q::kSlabs - 1) % Q::kSlabs);
+                    if (f == 0) {
+                        if (!Q::isX(s)) { // f16 record two main slabs ahead (t+2 >= taps: next chunk)
+                            const int t2 = Q::tap(s) + 2;
+                            const size_t o = (t2 >= G::kTaps ? Q::kRecChunk : 0) + Q::recOff(Q::slabOfTap(t2 % G::kTaps));
+#pragma unroll
+                            for (int j = 0; j < NFRAG; ++j) w4[t2 % 3][j] = wc[o * rs + wg4 + j * 64];
+                        }
+                        if (prevX) { // the MX set is free: request the next MX slab of this chunk
+                            const int p2 = (s == 0) ? 0 : Q::pair(s - 1) + 1;
+                            const size_t o = Q::recOff(Q::slabOfPair(p2));
+#pragma unroll
+                            for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) w8[j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
+                        }
+                    }
+                    NSG_M8_REQ(q + kD, abuf, nbuf)
+                    const int slot = q % kWin;
+                    if (Q::isX(s)) {
+                        const i32x8 xb = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, aw[slot][0]),
+                                                                 __builtin_bit_cast(i32x4_t, aw[slot][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int j = 0; j < NFRAG; ++j) {
+                            const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[j][0]),
+                                                                     __builtin_bit_cast(i32x4_t, w8[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+                            acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 0, 0, 0,
+                                                                                        kM8ScaleByte, 0, 127);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NFRAG; ++j)
+                            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                __builtin_bit_cast(f16x8, w4[Q::tap(s) % 3][j]), __builtin_bit_cast(f16x8, aw[slot][0]), acc[f][j], 0, 0, 0);
+                    }
+                    // issue order inside the step: fragment request(s), weight requests, MFMAs
+                    if (Q::isX(((q + kD) % kSteps) / G::kMF)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (f == 0 && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, NFRAG, 0);
+                    if (f == 0 && prevX) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NFRAG, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NFRAG, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            wc += (size_t)Q::kRecChunk * rs;
+        }
+#undef NSG_M8_REQ
+        __syncthreads(); // every wave is done reading before the epilogue reuses LDS
+    } else {
     // weight stream: record q = (kc*taps + tap)*2 + s, NFRAG 1-KiB records per wave, held
     // in a register ring (a record is requested whole slabs of MFMAs before its first use,
     // which is what covers the L2 latency).  16-bit / f32: one record per slab.  kF16x3: two
@@ -292,12 +444,6 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
         for (int j = 0; j < NFRAG; ++j) w[q % kWSets][j] = wp[(size_t)q * slabStride + j * 64];
     wp += (size_t)kLead * slabStride;
-
-    f32x4 acc[G::kMF][NFRAG];
-#pragma unroll
-    for (int f = 0; f < G::kMF; ++f)
-#pragma unroll
-        for (int j = 0; j < NFRAG; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     NSG_STAGE_LOAD(0)
     if (G::kBoards && zeroLds) {
@@ -449,6 +595,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         }
     }
     if constexpr (kFlow) __syncthreads(); // every wave is done reading before the epilogue reuses LDS
+    }
 
 #undef NSG_STAGE_LOAD
 #undef NSG_STAGE_WRITE
@@ -569,7 +716,15 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // byte offset, inside the row slice, of this lane's k-th 16-byte piece
         auto pieceOff = [&](int k) -> int {
             if constexpr (kSplit) return (g >> 1) * 128 + (g & 1) * 32 + (k & 1) * 16 + (k >> 1) * 64;
+            else if constexpr (kM8) // pieces 0,1: f16 hi; 2: e4m3(hi); 3: e4m3(lo * 2^12) of this lane's 16 channels
+                return (g >> 1) * 128 + (k < 2 ? (g & 1) * 32 + k * 16 : 64 + (k - 2) * 32 + (g & 1) * 16);
             else return g * (kRowB / 4) + k * 16;
+        };
+        // kF16m8, last trunk layer: the output is written in the kF16x3 layout (hi, f16 lo)
+        const bool outX3 = kM8 && A.outF16x3;
+        auto pieceOffOut = [&](int k) -> int {
+            if (kM8 && outX3) return (g >> 1) * 128 + (g & 1) * 32 + (k & 1) * 16 + (k >> 1) * 64;
+            return pieceOff(k);
         };
         const int lrow = lane / kPPR;   // lane-linear view: row within an instruction
         const int lpc = lane % kPPR;    //                   piece within the row
@@ -622,6 +777,19 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                                     v[k * 8 + 2 * i + 1] += f16BitsToF32((uint16_t)(rp[k][i] >> 16)) +
                                                             f16BitsToF32((uint16_t)(rp[2 + k][i] >> 16));
                                 }
+                        } else if constexpr (kM8) {
+                            constexpr float kLoInv = 1.0f / (float)(1 << kM8LoShift);
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) { // dword d of the lo piece = channels 4d .. 4d+3
+                                const f32x2 l01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)rp[3][d], false);
+                                const f32x2 l23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)rp[3][d], true);
+                                const uint32_t h01 = rp[d >> 1][(d & 1) * 2], h23 = rp[d >> 1][(d & 1) * 2 + 1];
+                                v[4 * d + 0] += f16BitsToF32((uint16_t)(h01 & 0xffffu)) + l01[0] * kLoInv;
+                                v[4 * d + 1] += f16BitsToF32((uint16_t)(h01 >> 16)) + l01[1] * kLoInv;
+                                v[4 * d + 2] += f16BitsToF32((uint16_t)(h23 & 0xffffu)) + l23[0] * kLoInv;
+                                v[4 * d + 3] += f16BitsToF32((uint16_t)(h23 >> 16)) + l23[1] * kLoInv;
+                            }
                         } else {
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
@@ -653,6 +821,40 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                                 op[k][i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
                                 op[2 + k][i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
                             }
+                    } else if constexpr (kM8) {
+                        if (outX3) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    uint16_t h0, l0, h1, l1;
+                                    splitF16(v[k * 8 + 2 * i], h0, l0);
+                                    splitF16(v[k * 8 + 2 * i + 1], h1, l1);
+                                    op[k][i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                                    op[2 + k][i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                                }
+                        } else {
+                            float hf[16], lf[16];
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) {
+                                const float x = fminf(fmaxf(v[c], -65000.f), 65000.f);
+                                const _Float16 h = (_Float16)x;
+                                const uint32_t hb = __builtin_bit_cast(uint16_t, h);
+                                if (c & 1) op[c >> 3][(c & 7) >> 1] |= hb << 16;
+                                else op[c >> 3][(c & 7) >> 1] = hb;
+                                hf[c] = __builtin_amdgcn_fmed3f((float)h, -448.f, 448.f);
+                                lf[c] = __builtin_amdgcn_fmed3f((x - (float)h) * (float)(1 << kM8LoShift), -448.f, 448.f);
+                            }
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[4 * d], hf[4 * d + 1], 0, false);
+                                h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[4 * d + 2], hf[4 * d + 3], h8, true);
+                                int l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[4 * d], lf[4 * d + 1], 0, false);
+                                l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[4 * d + 2], lf[4 * d + 3], l8, true);
+                                op[2][d] = (uint32_t)h8;
+                                op[3][d] = (uint32_t)l8;
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int k = 0; k < 2; ++k)
@@ -660,7 +862,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                             for (int i = 0; i < 4; ++i) op[k][i] = packPair<PREC>(v[k * 8 + 2 * i], v[k * 8 + 2 * i + 1]);
                     }
 #pragma unroll
-                    for (int k = 0; k < kNP; ++k) *reinterpret_cast<u32x4*>(lrowp + pieceOff(k)) = op[k];
+                    for (int k = 0; k < kNP; ++k) *reinterpret_cast<u32x4*>(lrowp + pieceOffOut(k)) = op[k];
                 }
             }
             // LDS image -> global, lane-linear: kRPI rows x kRowB contiguous bytes per instruction
@@ -850,6 +1052,7 @@ hipError_t launchDenseFp32(const Args& a, hipStream_t s);
 hipError_t launchDenseFp16(const Args& a, hipStream_t s);
 hipError_t launchDenseBf16(const Args& a, hipStream_t s);
 hipError_t launchConvF16x3(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkFp32(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkFp16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkBf16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);

@@ -1,0 +1,20 @@
+// mfma_tile_f16m8.hip -- kF16m8 (f16 main term + fp8 MX correction terms) instantiations of
+// the trunk convolution: full tiles only (4 fragments per wave).
+#include "mfma_tile.h"
+
+namespace nsg {
+namespace tile {
+
+hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStream_t s) {
+    const int gx = (batch + p.nb - 1) / p.nb;
+    if (p.nfrag != 4) return hipErrorInvalidValue;
+#define NSG_CASE(NB_, NW_) \
+    if (p.nb == NB_ && p.nwaves == NW_) return launchOne<kF16m8, kConv, NB_, 4, NW_>(a, gx, s);
+    NSG_CASE(2, 4) NSG_CASE(2, 3) NSG_CASE(2, 2) NSG_CASE(2, 1)
+    NSG_CASE(1, 4) NSG_CASE(1, 3) NSG_CASE(1, 2) NSG_CASE(1, 1)
+#undef NSG_CASE
+    return hipErrorInvalidValue;
+}
+
+} // namespace tile
+} // namespace nsg

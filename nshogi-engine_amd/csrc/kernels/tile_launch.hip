@@ -46,7 +46,7 @@ ConvPlan chooseConvPlan(int batch, int cout, int computeUnits, const ConvTuning&
         }
     }
 chosen:
-    const int kEnvNb = tune.nb, kEnvNwaves = tune.nwaves, kEnvNfrag = tune.nfrag;
+    const int kEnvNb = tune.nb, kEnvNwaves = tune.nwaves, kEnvNfrag = tune.fullTilesOnly ? 4 : tune.nfrag;
     if (kEnvNb == 1 || kEnvNb == 2) p.nb = kEnvNb;
     if (kEnvNfrag) {
         const int v = kEnvNfrag;
@@ -61,7 +61,7 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
                          const void* residual, void* y, int batch, int cin,
                          int cout, int relu, float accScale, int prec,
                          const ConvPlan& plan, hipStream_t stream,
-                         unsigned long long* stamps) {
+                         unsigned long long* stamps, bool outF16x3) {
     if (batch <= 0 || (cin * elemSize(prec)) % 128 != 0 || cout % 64 != 0)
         return hipErrorInvalidValue;
     tile::Args a{};
@@ -76,7 +76,9 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
     a.relu = relu;
     a.accScale = accScale;
     a.stamps = stamps;
+    a.outF16x3 = outF16x3 ? 1 : 0;
     switch (prec) {
+    case kF16m8: return tile::launchConvF16m8(a, batch, plan, stream);
     case kFp32: return tile::launchConvFp32(a, batch, plan, stream);
     case kFp16: return tile::launchConvFp16(a, batch, plan, stream);
     case kBf16: return tile::launchConvBf16(a, batch, plan, stream);
@@ -239,8 +241,82 @@ static inline uint16_t hostF32ToBf16(float f) {
 
 size_t tileWeightRecords(int taps, int kdim, int cout, int prec) {
     const int nkc = kdim / chunkChannels(prec);
-    return ((size_t)nkc * taps * recordsPerTap(prec) + 16) * (cout / 16) * 64; // + 16 zero records: deepest prefetch
+    return ((size_t)nkc * recordsPerChunk(taps, prec) + 16) * (cout / 16) * 64; // + 16 zero records: deepest prefetch
 }
+
+namespace {
+// OCP e4m3 (bias 7, max 448, no infinities), round to nearest even, saturating.
+uint8_t hostF32ToE4m3(float v) {
+    const uint8_t sign = std::signbit(v) ? 0x80 : 0;
+    float a = std::fabs(v);
+    if (!(a == a)) return sign | 0x7f;
+    if (a >= 448.f) return sign | 0x7e;
+    if (a < 0x1p-10f) return sign; // below half the smallest subnormal (2^-9)
+    int e;
+    (void)std::frexp(a, &e); // a = m * 2^e, m in [0.5, 1)
+    int ex = e - 1;          // a in [2^ex, 2^(ex+1))
+    if (ex < -6) ex = -6;    // subnormal range: step 2^-9
+    const float step = std::ldexp(1.f, ex - 3);
+    float q = std::nearbyint(a / step); // ties to even (default rounding mode)
+    float r = q * step;
+    if (r >= 448.f) return sign | 0x7e;
+    // re-derive exponent after rounding (may have carried)
+    int e2;
+    (void)std::frexp(r, &e2);
+    int ex2 = e2 - 1;
+    if (r < 0x1p-6f) { // subnormal
+        return sign | (uint8_t)std::lrint(r / 0x1p-9f);
+    }
+    const int mant = (int)std::lrint(r / std::ldexp(1.f, ex2 - 3)) - 8;
+    return sign | (uint8_t)(((ex2 + 7) << 3) | (mant & 7));
+}
+
+// kF16m8 conv weights (see kernels.h): per chunk the slabs m0 m1 X0 m2 m3 X1 ... in stream order.
+void packTileWeightsM8(WeightGetter get, const void* ctx, int taps, int kReal, int kdim, int cout,
+                       float scale, unsigned char* out) {
+    const int nkc = kdim / 32;
+    const int nft = cout / 16;
+    const size_t recBytes = (size_t)nft * 64 * 16; // one record set: nft fragments x 64 lanes x 16 B
+    auto chan = [](int nf, int rho) {
+        return (nf / kNfrag) * kNfrag * 16 + (rho >> 2) * 4 * kNfrag + (nf % kNfrag) * 4 + (rho & 3);
+    };
+    auto wval = [&](int n, int k, int t) { return (k < kReal && t < taps) ? get(ctx, n, k, t) * scale : 0.f; };
+    size_t r = 0; // record sets written so far
+    for (int c = 0; c < nkc; ++c) {
+        for (int t = 0; t < taps; ++t) {
+            // main slab: w_hi as 8 f16 per lane
+            for (int nf = 0; nf < nft; ++nf)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int rho = lane & 15, g = lane >> 4, n = chan(nf, rho);
+                    unsigned char* rec = out + r * recBytes + ((size_t)nf * 64 + lane) * 16;
+                    for (int i = 0; i < 8; ++i) {
+                        const _Float16 h = (_Float16)wval(n, c * 32 + 8 * g + i, t);
+                        memcpy(rec + i * 2, &h, 2);
+                    }
+                }
+            ++r;
+            const bool pairEnd = (t & 1) || (t == taps - 1);
+            if (!pairEnd) continue;
+            const int p = t / 2;
+            for (int nf = 0; nf < nft; ++nf)
+                for (int half = 0; half < 2; ++half)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int rho = lane & 15, g = lane >> 4, n = chan(nf, rho);
+                        const int tt = 2 * p + (g >> 1);
+                        unsigned char* rec = out + r * recBytes + (((size_t)nf * 2 + half) * 64 + lane) * 16;
+                        for (int i = 0; i < 16; ++i) {
+                            const float v = wval(n, c * 32 + 16 * half + i, tt);
+                            const _Float16 h = (_Float16)v;
+                            const float lo = v - (float)h;
+                            rec[i] = (g & 1) ? hostF32ToE4m3(std::ldexp((float)h, kM8WHiShift))
+                                             : hostF32ToE4m3(std::ldexp(lo, kM8WLoShift));
+                        }
+                    }
+            r += 2;
+        }
+    }
+}
+} // namespace
 
 void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
                      int kdim, int cout, int prec, float scale, void* dst) {
@@ -251,6 +327,10 @@ void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
     const int per = (prec == kFp32) ? 4 : 8; // values per record
     unsigned char* out = (unsigned char*)dst;
     memset(out, 0, tileWeightRecords(taps, kdim, cout, prec) * 16);
+    if (prec == kF16m8) {
+        packTileWeightsM8(get, ctx, taps, kReal, kdim, cout, scale, out);
+        return;
+    }
     for (int c = 0; c < nkc; ++c)
         for (int t = 0; t < taps; ++t)
             for (int s = 0; s < spt; ++s) {

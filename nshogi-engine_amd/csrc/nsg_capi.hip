@@ -250,7 +250,7 @@ int uploadLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int
     const size_t bytes = nsg::tileWeightRecords(taps, kdim, cout, prec) * 16;
     std::vector<unsigned char> host(bytes);
     float scale = 1.f;
-    if (prec == nsg::kF16x3) {
+    if (prec == nsg::kF16x3 || prec == nsg::kF16m8) {
         // power-of-two scale putting the largest |w| in [2^8, 2^9): hi and lo of every
         // weight that matters stay in f16's normal range; undone exactly by accScale
         float maxAbs = 0.f;
@@ -299,8 +299,10 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     void* x = act(ev->act[0].p, (size_t)81 * ev->F);
     void* y = act(ev->act[1].p, (size_t)81 * ev->F);
     void* z = act(ev->act[2].p, (size_t)81 * ev->F);
+    const int hprec = nsg::headPrecision(prec); // kF16m8: the last trunk layer writes the kF16x3 layout
     NSG_HIP(nsg::launchConv3x3(planes, ev->stem.w.p, (const float*)ev->stem.bias.p, nullptr, x, count,
-                               ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s));
+                               ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s, nullptr,
+                               hprec != prec && ev->blocks == 0));
     if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
     for (int k = 0; k < ev->blocks; ++k) {
         unsigned long long* st1 = nullptr;
@@ -316,7 +318,8 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
         NSG_HIP(nsg::launchConv3x3(x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p, nullptr, y, count,
                                    ev->F, ev->F, 1, ev->conv1[k].accScale, prec, plan, s, st1));
         NSG_HIP(nsg::launchConv3x3(y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p, x, z, count,
-                                   ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s, st2));
+                                   ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s, st2,
+                                   hprec != prec && k == ev->blocks - 1));
         void* t = x; x = z; z = t;
     }
     if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
@@ -326,9 +329,9 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     void* vfeat = act(ev->vfeat.p, (size_t)ev->fc1K);
     float* hidden = (float*)ev->hidden.p + (size_t)off * ev->vh;
     NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p, policy, vfeat, count, ev->F,
-                             ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, prec, s));
+                             ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, hprec, s));
     NSG_HIP(nsg::launchDense(vfeat, ev->fc1.w.p, (const float*)ev->fc1.bias.p, hidden, count, ev->fc1K,
-                             ev->vh, 1, ev->fc1.accScale, prec, s));
+                             ev->vh, 1, ev->fc1.accScale, hprec, s));
     NSG_HIP(nsg::launchValueOut(hidden, (const float*)ev->fc2W.p, (const float*)ev->fc2B.p,
                                 (float*)ev->value.p + off, (float*)ev->draw.p + off, count, ev->vh, s));
     return NSG_OK;
@@ -338,7 +341,9 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     const int B = (int)n;
     hipStream_t s = ev->stream;
     // the tile plan is chosen for the whole batch: all chains run concurrently
-    const nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount, ev->tuning);
+    nsg::ConvTuning tune = ev->tuning;
+    tune.fullTilesOnly = (ev->prec == nsg::kF16m8);
+    const nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount, tune);
 
     const bool prof = ev->profile;
     if (prof && ev->evUsed + 4 > (int)ev->ev.size()) {
@@ -482,7 +487,7 @@ int nsg_destroy(nsg_evaluator* ev) {
 int nsg_set_precision(nsg_evaluator* ev, int precision) {
     if (!ev) return fail(NSG_E_INVALID, "null evaluator");
     if (ev->loaded) return fail(NSG_E_INVALID, "precision must be chosen before nsg_load");
-    if (precision < NSG_PRECISION_FP32 || precision > NSG_PRECISION_F16X3)
+    if (precision < NSG_PRECISION_FP32 || precision > NSG_PRECISION_F16M8)
         return fail(NSG_E_INVALID, "unknown precision %d", precision);
     ev->prec = precision;
     return NSG_OK;
@@ -539,12 +544,12 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
         for (int i = 0; i < nv.vc; ++i) hb[i] = bias[i];
         for (int i = 0; i < nv.pc; ++i) hb[nv.vc + i] = nv.polB[i];
         HeadsCtx c{nv.valW, scale.data(), nv.polW, nv.F, nv.vc, nv.pc};
-        if ((rc = uploadLayer(headsGet, &c, 1, nv.F, nv.F, ev->headsCout, nv.vc + nv.pc, prec, hb, &ev->heads))) return rc;
+        if ((rc = uploadLayer(headsGet, &c, 1, nv.F, nv.F, ev->headsCout, nv.vc + nv.pc, nsg::headPrecision(prec), hb, &ev->heads))) return rc;
     }
     {
         std::vector<float> b1(nv.fc1B, nv.fc1B + nv.vh);
         Fc1Ctx c{nv.fc1W, nv.vc};
-        if ((rc = uploadLayer(fc1Get, &c, 1, 81 * nv.vc, ev->fc1K, nv.vh, nv.vh, prec, b1, &ev->fc1))) return rc;
+        if ((rc = uploadLayer(fc1Get, &c, 1, 81 * nv.vc, ev->fc1K, nv.vh, nv.vh, nsg::headPrecision(prec), b1, &ev->fc1))) return rc;
     }
     if ((rc = ev->fc2W.alloc((size_t)2 * nv.vh * 4, false))) return rc;
     if ((rc = ev->fc2B.alloc(8, false))) return rc;
@@ -575,7 +580,7 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
         NSG_HIP(hipMemcpy(ev->trunkLayers.p, host.data(), host.size(), hipMemcpyHostToDevice));
         ev->trunkLayerCount = nl;
         const char* env = getenv("NSG_TRUNK_KERNEL");
-        ev->useTrunkKernel = (env && env[0] == '1');
+        ev->useTrunkKernel = (env && env[0] == '1') && prec != nsg::kF16m8;
     }
     NSG_HIP(hipDeviceSynchronize());
     ev->loaded = true;
@@ -722,7 +727,7 @@ int nsg_download_trunk(nsg_evaluator* ev, size_t batch_size, float* dst) {
     const size_t bytes = batch_size * ev->F * 81 * sizeof(float);
     if (ev->scratch.bytes < bytes && (rc = ev->scratch.alloc(bytes, false))) return rc;
     NSG_HIP(nsg::launchActToNCHW(ev->trunkOut, (float*)ev->scratch.p, (int)batch_size, ev->F,
-                                 ev->prec, ev->stream));
+                                 nsg::headPrecision(ev->prec), ev->stream));
     NSG_HIP(hipMemcpyAsync(dst, ev->scratch.p, bytes, hipMemcpyDeviceToHost, ev->stream));
     NSG_HIP(hipStreamSynchronize(ev->stream));
     return NSG_OK;

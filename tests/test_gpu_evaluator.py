@@ -116,6 +116,37 @@ def test_f16x3_full_size_properties(nsg, oracle):
     assert ((v >= 0) & (v <= 1)).all() and ((d >= 0) & (d <= 1)).all() and np.isfinite(p).all()
 
 
+@pytest.mark.parametrize("blocks,channels,batch", [(1, 64, 3), (2, 128, 9), (2, 192, 5), (3, 256, 70), (1, 384, 4)])
+def test_f16m8_vs_oracle(nsg, oracle, blocks, channels, batch):
+    """f16 main term + fp8 MX correction terms (trunk convolutions): outputs and the trunk
+    activation against the oracle, held to the north_star's 1e-3 (measured ~1e-4)."""
+    ev, blob = make(nsg, blocks, channels, batch, precision="f16m8", seed=40 + channels)
+    net = oracle.net(blob)
+    bb = nsg.synth.random_batch(batch, 86, seed=11, garbage=True)
+    out = ev.compute_blocking(bb)
+    n = min(batch, 6)
+    ref = net.evaluate(bb[:n])
+    check((out[0][:n], out[1][:n], out[2][:n]), ref, TOL)
+    trunk = ev.download_trunk(n)
+    _, _, _, t_ref = net.forward_planes(oracle.extract_bits(bb[:n]), want_trunk=True)
+    assert float(np.abs(trunk - t_ref).max()) < TOL * max(1.0, float(np.abs(t_ref).max()))
+
+
+def test_f16m8_full_size_properties(nsg, oracle):
+    """kF16m8 at BASELINE's full size (20x256, B=512): a sample of boards against the
+    oracle at the north_star tolerance, bit-exact independence from batch composition."""
+    ev, blob = make(nsg, 20, 256, 512, precision="f16m8", seed=4, bn="identity")
+    bb = nsg.synth.random_batch(512, 86, seed=8)
+    p, v, d = ev.compute_blocking(bb)
+    idx = [0, 255, 511]
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
+    perm = np.random.default_rng(1).permutation(512)
+    p2, v2, d2 = ev.compute_blocking(bb[perm])
+    np.testing.assert_array_equal(p2, p[perm])
+    np.testing.assert_array_equal(v2, v[perm])
+    assert ((v >= 0) & (v <= 1)).all() and ((d >= 0) & (d <= 1)).all() and np.isfinite(p).all()
+
+
 def test_f16x3_extreme_magnitudes(nsg, oracle):
     """Weights spanning many binades (the per-tensor power-of-two scale must keep
     hi/lo in f16 range) and large activations (BN gamma 8): still f32-equivalent."""
@@ -184,7 +215,7 @@ def test_error_behaviour(nsg, tmp_path):
     assert ev2.info()["loaded"] == 1 and ev2.info()["channels"] == 64
 
 
-@pytest.mark.parametrize("precision,tol", [("f16x3", 1e-4), ("fp16", 2e-2), ("bf16", 1.5e-1)])
+@pytest.mark.parametrize("precision,tol", [("f16x3", 1e-4), ("f16m8", 1e-3), ("fp16", 2e-2), ("bf16", 1.5e-1)])
 def test_reduced_precision_paths(nsg, oracle, precision, tol):
     """16-bit operand paths (f32 accumulate).  f16x3 (split hi/lo, three MFMAs per
     MAC) is f32-equivalent and is held to 1e-4; plain f16/bf16 are looser than the
