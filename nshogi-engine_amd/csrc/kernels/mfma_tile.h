@@ -71,7 +71,7 @@ struct Geom {
     static constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
     static constexpr int kBuf = 8 * kPlane;  // one 128-byte channel chunk
     static constexpr int kLds = 2 * kBuf;    // double buffered
-    static constexpr int kLdsAlloc = kLds + 16; // + one trash slot for masked staging lanes
+    static constexpr int kLdsAlloc = kLds + 1024; // + one trash slot per lane for masked staging lanes
     static constexpr int kThreads = NWAVES * 64;
     static constexpr int kItems = (2 * kMF + NWAVES - 1) / NWAVES;
     static constexpr int kTaps = kBoards ? 9 : 1;
@@ -259,11 +259,20 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         size_t grow = row0 + mm;
         if (grow > lastRow) grow = lastRow;
         srcOff[k] = grow * (size_t)A.kdim * ES + c * 16;
-        // masked lanes store to the trash slot behind both buffers: the store
+        // masked lanes store to their own trash slot behind both buffers (one shared slot made
+        // every masked store a 64-way same-address conflict that stalled the whole LDS): the store
         // stays unconditional, so st[] stays in registers
-        dstOff[k] = itemOk[k] ? c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16 : G::kLds;
+        dstOff[k] = itemOk[k] ? c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16 : G::kLds + lane * 16;
     }
     u32x4 st[G::kItems];
+    // Pins every accumulator to an AGPR at the top of a K-chunk iteration.  Without it the
+    // register allocator gives the loop-carried accumulators different registers at the
+    // top and the bottom of the unrolled body and rotates all 176 of them through
+    // v_accvgpr_read/mov (~360 instructions per chunk, each waiting on the matrix pipe).
+#define NSG_PIN_ACC_AGPR                                                                 \
+    _Pragma("unroll") for (int f = 0; f < G::kMF; ++f) {                                 \
+        _Pragma("unroll") for (int j = 0; j < NFRAG; ++j) asm volatile("" : "+a"(acc[f][j])); \
+    }
     // (macros, not lambdas: a by-reference capture keeps st[] in scratch)
 #define NSG_STAGE_LOAD(KC)                                                               \
     _Pragma("unroll") for (int k = 0; k < G::kItems; ++k) {                              \
@@ -287,14 +296,22 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // window of kWin register slots and are requested kD steps ahead (a step is 4 MFMAs:
         // 64 clk for an f16 slab, 128 clk for an MX slab), across slab and chunk boundaries;
         // the f16 weight records sit in three register sets (requested two main slabs
-        // ahead), the MX records in one (requested as soon as the previous MX slab is done).
+        // ahead), the MX records in two (X_p+1 requested at the top of X_p).
         using Q = M8Seq<G::kTaps>;
         static_assert(G::kTaps % 3 == 0, "three f16 weight sets must carry across chunks");
         constexpr int kSteps = Q::kSlabs * G::kMF;
-        constexpr int kWin = 7, kD = 5;
+        constexpr int kWin = 7, kD = 5; // (11 slots / 9 steps of lead: no faster)
         static_assert(kSteps % kWin == 0, "window slot must carry across chunks");
-        constexpr int kWriteStep = 4 * G::kMF;      // next chunk's tile -> LDS
+        // Next chunk's tile.  All workgroups run in lock-step, so tile loads issued at one
+        // point of the chunk hit HBM/MALL as one 5 MB burst and take > 2 us; and VMEM loads
+        // return in order, so every weight record requested behind them waits that long too.
+        // The tile's items are therefore requested one per slab over slabs 2..7 (X0 m2 m3 X1
+        // m4 m5), each AFTER its step's weight requests, and written to LDS at the top of the
+        // last MX slab, just before the barrier.
+        constexpr int kLoadSlab0 = 2, kLoadSlabs = 6;
+        constexpr int kWriteStep = Q::slabOfPair(Q::kNX - 1) * G::kMF;
         constexpr int kBarStep = kSteps - kD;       // first step that requests next-chunk fragments
+        static_assert(kWriteStep < kBarStep && (kLoadSlab0 + kLoadSlabs) * G::kMF < kWriteStep, "tile staging order");
         auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
         // MX operand of lane (li, g): 32 fp8 bytes of tap 2p + (g>>1); g&1 ? lo bytes : hi bytes
         int offp8[Q::kNX];
@@ -303,12 +320,16 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             const int t0 = 2 * p, t1 = (2 * p + 1 < G::kTaps) ? 2 * p + 1 : 2 * p; // (missing tap: its weights are zero)
             offp8[p] = (4 + 2 * (g & 1) - g) * G::kPlane + ((g >> 1) ? tapOff(t1) : tapOff(t0));
         }
+#ifdef NSG_EXP_HOTW
+        const size_t rs = 0; // diagnostic: every weight record an L1 hit (results are wrong)
+#else
         const size_t rs = (size_t)nft * 64; // one record set
+#endif
         const u32x4* wc = A.w + lane;
         const size_t wg4 = (size_t)waveGroup * NFRAG * 64;  // this wave's records inside a main set
         const size_t wg8 = wg4 * 2;                         //                          an MX pair of sets
         u32x4 w4[3][NFRAG];
-        u32x4 w8[NFRAG][2];
+        u32x4 w8[2][NFRAG][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -346,15 +367,26 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         for (int kc = 0; kc < nkc; ++kc) {
             const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
             const unsigned char* nbuf = smem + ((kc + 1) & 1) * G::kBuf;
-            NSG_STAGE_LOAD(kc + 1 < nkc ? kc + 1 : kc)
+            NSG_PIN_ACC_AGPR
 #pragma unroll
             for (int s = 0; s < Q::kSlabs; ++s) {
 #pragma unroll
                 for (int f = 0; f < G::kMF; ++f) {
                     const int q = s * G::kMF + f;
+#ifdef NSG_DIAG_STAMPS
+                    // slab timeline of workgroup 0 / wave 0, stored behind the per-workgroup stamps
+                    if (f == 0 && A.stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+                        A.stamps[2048 + kc * 16 + s] = __builtin_amdgcn_s_memtime();
+#endif
+#if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOWRITE)
                     if (q == kWriteStep) { NSG_STAGE_WRITE((kc + 1) & 1) }
-                    if (q == kBarStep) __syncthreads();
-                    const bool prevX = Q::isX((s + Q::kSlabs - 1) % Q::kSlabs);
+#endif
+#if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOBAR)
+                    if (q == kBarStep) __syncthreads(); // publishes the tile written at kWriteStep
+#endif
+                    // MX records: two sets.  X0 is requested at the top of the chunk (set 0 is free once
+                    // the previous chunk's last MX slab is done), X_p+1 at the top of X_p.
+                    const bool reqX = (s == 0) || (Q::isX(s) && Q::pair(s) + 1 < Q::kNX);
                     if (f == 0) {
                         if (!Q::isX(s)) { // f16 record two main slabs ahead (t+2 >= taps: next chunk)
                             const int t2 = Q::tap(s) + 2;
@@ -362,24 +394,33 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
                             for (int j = 0; j < NFRAG; ++j) w4[t2 % 3][j] = wc[o * rs + wg4 + j * 64];
                         }
-                        if (prevX) { // the MX set is free: request the next MX slab of this chunk
-                            const int p2 = (s == 0) ? 0 : Q::pair(s - 1) + 1;
+                        if (reqX) {
+                            const int p2 = (s == 0) ? 0 : Q::pair(s) + 1;
                             const size_t o = Q::recOff(Q::slabOfPair(p2));
 #pragma unroll
                             for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
-                                for (int h = 0; h < 2; ++h) w8[j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
+                                for (int h = 0; h < 2; ++h) w8[p2 & 1][j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
                         }
                     }
+#if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOLOAD)
+                    if (f == 0 && s >= kLoadSlab0 && s < kLoadSlab0 + kLoadSlabs) {
+#pragma unroll
+                        for (int k = s - kLoadSlab0; k < G::kItems; k += kLoadSlabs)
+                            st[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)(kc + 1 < nkc ? kc + 1 : kc) * 128);
+                    }
+#endif
+#ifndef NSG_EXP_NOLDS
                     NSG_M8_REQ(q + kD, abuf, nbuf)
+#endif
                     const int slot = q % kWin;
                     if (Q::isX(s)) {
                         const i32x8 xb = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, aw[slot][0]),
                                                                  __builtin_bit_cast(i32x4_t, aw[slot][1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                         for (int j = 0; j < NFRAG; ++j) {
-                            const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[j][0]),
-                                                                     __builtin_bit_cast(i32x4_t, w8[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+                            const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[Q::pair(s) & 1][j][0]),
+                                                                     __builtin_bit_cast(i32x4_t, w8[Q::pair(s) & 1][j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
                             acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 0, 0, 0,
                                                                                         kM8ScaleByte, 0, 127);
                         }
@@ -389,12 +430,16 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                             acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                                 __builtin_bit_cast(f16x8, w4[Q::tap(s) % 3][j]), __builtin_bit_cast(f16x8, aw[slot][0]), acc[f][j], 0, 0, 0);
                     }
-                    // issue order inside the step: fragment request(s), weight requests, MFMAs
+                    // issue order inside the step: the first MFMA, then the requests (they issue in its
+                    // shadow instead of between two steps), then the other MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     if (Q::isX(((q + kD) % kSteps) / G::kMF)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     if (f == 0 && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, NFRAG, 0);
-                    if (f == 0 && prevX) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NFRAG, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, NFRAG, 0);
+                    if (f == 0 && reqX) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NFRAG, 0);
+                    if (f == 0 && s >= kLoadSlab0 && s < kLoadSlab0 + kLoadSlabs)
+                        __builtin_amdgcn_sched_group_barrier(0x020, (G::kItems + kLoadSlabs - 1) / kLoadSlabs, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NFRAG - 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -598,6 +643,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     }
 
 #undef NSG_STAGE_LOAD
+#undef NSG_PIN_ACC_AGPR
 #undef NSG_STAGE_WRITE
     NSG_STAMP(2);
 

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Diagnostic (libnsg_diag.so): cycles per slab of the kF16m8 main loop for workgroup 0 / wave 0,
+averaged over the trunk layers -- shows where in the chunk the matrix pipe waits."""
+import ctypes, importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["NSG_LIB"] = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "libnsg_diag.so")
+nsg = importlib.import_module("nshogi-engine_amd")
+blocks, ch, B = 20, 256, 512
+ev = nsg.Evaluator(0, B, 86, precision="f16m8")
+ev.load_memory(nsg.weights.to_blob(nsg.weights.make_random(blocks, ch, seed=0)))
+lib = nsg.load_library()
+lib.nsg_debug_stamps_enable.argtypes = [ctypes.c_void_p]; lib.nsg_debug_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+ev.upload_features(nsg.synth.random_batch(B, 86, seed=1))
+for _ in range(3): ev.forward_resident(B)
+assert lib.nsg_debug_stamps_enable(ev._h) == 0
+for _ in range(2): ev.forward_resident(B)
+buf = np.zeros((2 * blocks, 4096 * 8), dtype=np.uint64)
+assert lib.nsg_debug_stamps_read(ev._h, buf.ctypes.data) == 0
+names = "m0 m1 X0 m2 m3 X1 m4 m5 X2 m6 m7 X3 m8 X4".split()
+t = buf[2:, 2048:2048 + 8 * 16].astype(np.float64).reshape(-1, 8, 16)[:, :, :14]   # layer, chunk, slab
+d = np.diff(t.reshape(t.shape[0], 8 * 14), axis=1)                                 # consecutive slab starts
+d = np.concatenate([d, np.full((d.shape[0], 1), np.nan)], axis=1).reshape(-1, 8, 14)
+print("ideal: m 704, X 1408 cycles")
+print("slab  " + " ".join(f"{n:>6s}" for n in names))
+for kc in range(8):
+    print(f"kc={kc}  " + " ".join(f"{np.nanmean(d[:, kc, s]):6.0f}" for s in range(14)))
+m = np.nanmean(d[:, 1:7, :], axis=(0, 1))
+print("mean  " + " ".join(f"{x:6.0f}" for x in m), " chunk total", round(float(m.sum())))
