@@ -94,6 +94,7 @@ def load_library():
     lib.nsg_get_info.argtypes = [vp, ctypes.POINTER(_Info)]
     ip = ctypes.POINTER(ctypes.c_int)
     lib.nsg_get_last_plan.argtypes = [vp, ip, ip, ip, ip]
+    lib.nsg_get_last_trunk_precision.argtypes = [vp, ip]
     lib.nsg_cpu_executor_create.argtypes = [i, ctypes.c_uint64, ctypes.POINTER(vp)]
     lib.nsg_cpu_executor_destroy.argtypes = [vp]
     lib.nsg_cpu_executor_compute.argtypes = [vp, vp, sz, vp, vp, vp]
@@ -238,8 +239,12 @@ class Evaluator:
         """Launch plan of the most recent forward pass (nsg_get_last_plan)."""
         v = [ctypes.c_int() for _ in range(4)]
         _check(self._lib.nsg_get_last_plan(self._h, *[ctypes.byref(x) for x in v]))
-        return dict(zip(("boards_per_group", "fragments_per_wave", "waves_per_group", "chains"),
-                        (x.value for x in v)))
+        d = dict(zip(("boards_per_group", "fragments_per_wave", "waves_per_group", "chains"),
+                     (x.value for x in v)))
+        tp = ctypes.c_int()
+        _check(self._lib.nsg_get_last_trunk_precision(self._h, ctypes.byref(tp)))
+        d["trunk_precision"] = {v: k for k, v in _PREC_NAMES.items() if k not in ("f32", "f16")}.get(tp.value, tp.value)
+        return d
 
 
 class CpuExecutor:

@@ -179,10 +179,11 @@ struct Args {
 
 // Single-board conv tiles are small enough for two workgroups per CU (two waves
 // per SIMD): the second argument caps registers at 256 so both fit.
-template <int MODE, int SIZE, int NWAVES, int NFRAG = 4>
+template <int MODE, int SIZE, int NWAVES, int NFRAG = 4, int PREC = 0>
 constexpr int minWavesPerSimd() {
-    // (two boards with 2 fragments per wave would spill at 256 registers: measured slower)
-    return (MODE == kConv && SIZE == 1 && (NWAVES >= 3 || NFRAG <= 2)) ? 2 : 1;
+    // (two boards with 2 fragments per wave would spill at 256 registers: measured slower;
+    // the kF16m8 loop needs ~450 registers at any tile size)
+    return (MODE == kConv && SIZE == 1 && (NWAVES >= 3 || NFRAG <= 2) && PREC != kF16m8) ? 2 : 1;
 }
 
 // kF16m8 slab sequence of one channel chunk: m0 m1 X0 m2 m3 X1 ... (m_t: f16 main term of
@@ -987,7 +988,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 }
 
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES>
-__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG>())) void tileKernel(const Args A) {
+__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG, PREC>())) void tileKernel(const Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0>(A, smem, true);
 }

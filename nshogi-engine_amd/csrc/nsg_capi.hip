@@ -191,6 +191,11 @@ struct nsg_evaluator {
 
     ConvLayer stem;
     std::vector<ConvLayer> conv1, conv2;
+    // kF16m8 evaluators also hold the trunk in kF16x3 form: batches too small for full
+    // tiles (4 fragments per wave) run the kF16x3 small-tile kernels instead
+    ConvLayer stemX3;
+    std::vector<ConvLayer> conv1X3, conv2X3;
+    int lastTrunkPrec = -1; // precision the most recent forward ran its trunk in
     ConvLayer heads;
     ConvLayer fc1;
     DevBuf fc2W, fc2B;
@@ -288,7 +293,13 @@ __global__ void delayKernel(unsigned long long ticks) {
 // One chain = the whole forward for boards [off, off + count) on stream `s`.
 int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& plan, hipStream_t s,
                  bool stampsOk, hipEvent_t trunkBegin = nullptr, hipEvent_t trunkEnd = nullptr) {
-    const int prec = ev->prec;
+    // kF16m8 runs full tiles only; smaller launch plans use the kF16x3 copy of the trunk
+    const bool x3Fallback = (ev->prec == nsg::kF16m8 && plan.nfrag != 4);
+    const int prec = x3Fallback ? (int)nsg::kF16x3 : ev->prec;
+    const ConvLayer& stem = x3Fallback ? ev->stemX3 : ev->stem;
+    const std::vector<ConvLayer>& conv1 = x3Fallback ? ev->conv1X3 : ev->conv1;
+    const std::vector<ConvLayer>& conv2 = x3Fallback ? ev->conv2X3 : ev->conv2;
+    if (off == 0) ev->lastTrunkPrec = prec;
     const size_t es = (size_t)nsg::elemSize(prec);
     auto act = [&](void* base, size_t rowElems) { return (void*)((unsigned char*)base + (size_t)off * rowElems * es); };
     const uint64_t* input = (const uint64_t*)ev->input.p + (size_t)off * ev->numChannels * 2;
@@ -300,8 +311,8 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     void* y = act(ev->act[1].p, (size_t)81 * ev->F);
     void* z = act(ev->act[2].p, (size_t)81 * ev->F);
     const int hprec = nsg::headPrecision(prec); // kF16m8: the last trunk layer writes the kF16x3 layout
-    NSG_HIP(nsg::launchConv3x3(planes, ev->stem.w.p, (const float*)ev->stem.bias.p, nullptr, x, count,
-                               ev->cpad, ev->F, 1, ev->stem.accScale, prec, plan, s, nullptr,
+    NSG_HIP(nsg::launchConv3x3(planes, stem.w.p, (const float*)stem.bias.p, nullptr, x, count,
+                               ev->cpad, ev->F, 1, stem.accScale, prec, plan, s, nullptr,
                                hprec != prec && ev->blocks == 0));
     if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
     for (int k = 0; k < ev->blocks; ++k) {
@@ -315,10 +326,10 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
 #else
         (void)stampsOk;
 #endif
-        NSG_HIP(nsg::launchConv3x3(x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p, nullptr, y, count,
-                                   ev->F, ev->F, 1, ev->conv1[k].accScale, prec, plan, s, st1));
-        NSG_HIP(nsg::launchConv3x3(y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p, x, z, count,
-                                   ev->F, ev->F, 1, ev->conv2[k].accScale, prec, plan, s, st2,
+        NSG_HIP(nsg::launchConv3x3(x, conv1[k].w.p, (const float*)conv1[k].bias.p, nullptr, y, count,
+                                   ev->F, ev->F, 1, conv1[k].accScale, prec, plan, s, st1));
+        NSG_HIP(nsg::launchConv3x3(y, conv2[k].w.p, (const float*)conv2[k].bias.p, x, z, count,
+                                   ev->F, ev->F, 1, conv2[k].accScale, prec, plan, s, st2,
                                    hprec != prec && k == ev->blocks - 1));
         void* t = x; x = z; z = t;
     }
@@ -341,9 +352,7 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     const int B = (int)n;
     hipStream_t s = ev->stream;
     // the tile plan is chosen for the whole batch: all chains run concurrently
-    nsg::ConvTuning tune = ev->tuning;
-    tune.fullTilesOnly = (ev->prec == nsg::kF16m8);
-    const nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount, tune);
+    const nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount, ev->tuning);
 
     const bool prof = ev->profile;
     if (prof && ev->evUsed + 4 > (int)ev->ev.size()) {
@@ -526,16 +535,24 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
     {
         Conv3Ctx c{nv.stemW, scale.data(), nv.cin};
         if ((rc = uploadLayer(conv3Get, &c, 9, nv.cin, ev->cpad, nv.F, nv.F, prec, bias, &ev->stem))) return rc;
+        if (prec == nsg::kF16m8 &&
+            (rc = uploadLayer(conv3Get, &c, 9, nv.cin, ev->cpad, nv.F, nv.F, nsg::kF16x3, bias, &ev->stemX3))) return rc;
     }
     ev->conv1.clear(); ev->conv2.clear();
     ev->conv1.resize(nv.blocks); ev->conv2.resize(nv.blocks);
+    ev->conv1X3.clear(); ev->conv2X3.clear();
+    if (prec == nsg::kF16m8) { ev->conv1X3.resize(nv.blocks); ev->conv2X3.resize(nv.blocks); }
     for (int k = 0; k < nv.blocks; ++k) {
         foldBn(nv.bn1[k], nv.F, nv.eps, &scale, &bias);
         Conv3Ctx c1{nv.w1[k], scale.data(), nv.F};
         if ((rc = uploadLayer(conv3Get, &c1, 9, nv.F, nv.F, nv.F, nv.F, prec, bias, &ev->conv1[k]))) return rc;
+        if (prec == nsg::kF16m8 &&
+            (rc = uploadLayer(conv3Get, &c1, 9, nv.F, nv.F, nv.F, nv.F, nsg::kF16x3, bias, &ev->conv1X3[k]))) return rc;
         foldBn(nv.bn2[k], nv.F, nv.eps, &scale, &bias);
         Conv3Ctx c2{nv.w2[k], scale.data(), nv.F};
         if ((rc = uploadLayer(conv3Get, &c2, 9, nv.F, nv.F, nv.F, nv.F, prec, bias, &ev->conv2[k]))) return rc;
+        if (prec == nsg::kF16m8 &&
+            (rc = uploadLayer(conv3Get, &c2, 9, nv.F, nv.F, nv.F, nv.F, nsg::kF16x3, bias, &ev->conv2X3[k]))) return rc;
     }
     // heads: [value conv (BN folded) | policy conv | zero pad]
     {
@@ -766,6 +783,12 @@ int nsg_get_last_plan(nsg_evaluator* ev, int* nb, int* nfrag, int* nwaves, int* 
     if (nfrag) *nfrag = ev->lastPlan.nfrag;
     if (nwaves) *nwaves = ev->lastPlan.nwaves;
     if (chains) *chains = ev->lastChains;
+    return NSG_OK;
+}
+
+int nsg_get_last_trunk_precision(nsg_evaluator* ev, int* precision) {
+    if (!ev || !precision) return fail(NSG_E_INVALID, "null argument");
+    *precision = ev->lastTrunkPrec;
     return NSG_OK;
 }
 

@@ -117,9 +117,10 @@ def test_f16x3_full_size_properties(nsg, oracle):
 
 
 @pytest.mark.parametrize("blocks,channels,batch", [(1, 64, 3), (2, 128, 9), (2, 192, 5), (3, 256, 70), (1, 384, 4)])
-def test_f16m8_vs_oracle(nsg, oracle, blocks, channels, batch):
+def test_f16m8_vs_oracle(nsg, oracle, monkeypatch, blocks, channels, batch):
     """f16 main term + fp8 MX correction terms (trunk convolutions): outputs and the trunk
     activation against the oracle, held to the north_star's 1e-3 (measured ~1e-4)."""
+    monkeypatch.setenv("NSG_CONV_NFRAG", "4")  # full tiles even at these small batches
     ev, blob = make(nsg, blocks, channels, batch, precision="f16m8", seed=40 + channels)
     net = oracle.net(blob)
     bb = nsg.synth.random_batch(batch, 86, seed=11, garbage=True)
@@ -127,9 +128,25 @@ def test_f16m8_vs_oracle(nsg, oracle, blocks, channels, batch):
     n = min(batch, 6)
     ref = net.evaluate(bb[:n])
     check((out[0][:n], out[1][:n], out[2][:n]), ref, TOL)
+    assert ev.last_plan()["trunk_precision"] == "f16m8"
     trunk = ev.download_trunk(n)
     _, _, _, t_ref = net.forward_planes(oracle.extract_bits(bb[:n]), want_trunk=True)
     assert float(np.abs(trunk - t_ref).max()) < TOL * max(1.0, float(np.abs(t_ref).max()))
+
+
+def test_f16m8_small_batches_run_as_f16x3(nsg, oracle):
+    """An f16m8 evaluator keeps the trunk in both forms: batches too small for full tiles
+    take the f16x3 small-tile kernels (f32-equivalent), larger ones the MX path."""
+    ev, blob = make(nsg, 2, 256, 300, precision="f16m8", seed=44)
+    net = oracle.net(blob)
+    bb = nsg.synth.random_batch(300, 86, seed=12)
+    p, v, d = ev.compute_blocking(bb[:16])
+    assert ev.last_plan()["trunk_precision"] == "f16x3"
+    check((p[:4], v[:4], d[:4]), net.evaluate(bb[:4]), 1e-4)
+    p, v, d = ev.compute_blocking(bb)
+    assert ev.last_plan()["trunk_precision"] == "f16m8"
+    idx = [0, 150, 299]
+    check((p[idx], v[idx], d[idx]), net.evaluate(bb[idx]), TOL)
 
 
 def test_f16m8_full_size_properties(nsg, oracle):
