@@ -29,8 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Default precision f16x3: the fastest path that meets the north_star's 1e-3 parity
-# (measured 5e-6 vs the CPU oracle, like the exact-f32 path; plain f16 / bf16 do not).
+# Default precision f16m8: the fastest path that meets the north_star's 1e-3 parity bar
+# (measured 1.3e-4 vs the CPU oracle on this net; f16x3 and f32 measure 5e-6 and are reported
+# beside it; plain f16 / bf16 do not meet the bar).
 # MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2516.6, "bf16": 2516.6, "f16x3": 2516.6, "f16m8": 2516.6}
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16", "bf16": "bf16", "f16x3": "f16x3 (split f16 hi/lo, f32 accumulate)",
@@ -137,7 +138,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--net", default="20x256", help="blocks x channels, e.g. 10x192, 20x256, 40x384")
     ap.add_argument("--batch", type=int, default=512)
-    ap.add_argument("--precision", default=os.environ.get("NSG_BENCH_PRECISION", "f16x3"),
+    ap.add_argument("--precision", default=os.environ.get("NSG_BENCH_PRECISION", "f16m8"),
                     choices=["fp32", "fp16", "bf16", "f16x3", "f16m8"])
     ap.add_argument("--selfplay-seconds", type=float, default=30.0,
                     help="length of the self-play leg (metric #2, games/sec); 0 disables it")

@@ -374,8 +374,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
                 for (int f = 0; f < G::kMF; ++f) {
                     const int q = s * G::kMF + f;
-#ifdef NSG_DIAG_STAMPS
+#ifdef NSG_DIAG_SLABS
                     // slab timeline of workgroup 0 / wave 0, stored behind the per-workgroup stamps
+                    // (its s_memtime drains the fragment window: a separate diagnostic build)
                     if (f == 0 && A.stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
                         A.stamps[2048 + kc * 16 + s] = __builtin_amdgcn_s_memtime();
 #endif

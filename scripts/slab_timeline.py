@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (libnsg_diag.so): cycles per slab of the kF16m8 main loop for workgroup 0 / wave 0,
+"""Diagnostic (libnsg_diag.so built by `make diag_slabs`): cycles per slab of the kF16m8 main loop for workgroup 0 / wave 0,
 averaged over the trunk layers -- shows where in the chunk the matrix pipe waits."""
 import ctypes, importlib, os, sys
 import numpy as np

@@ -3,7 +3,7 @@
 of boards (test infrastructure; writes a JSON line)."""
 import argparse, importlib, json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib
 

@@ -5,7 +5,7 @@ power-of-two scales, activations stored as (f16 hi, fp8(x_hi), fp8(x_lo * 2^SL))
 residual stream carries hi + dequantised lo.  Prints max/rms error of the policy logits
 against float64 for f16, f16x3 and f16m8 on the synthetic 20x256 net."""
 import importlib, sys, numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 nsg = importlib.import_module('nshogi-engine_amd'); import oracle_lib
 torch.set_num_threads(8)
 SL, SW, SH = 12, 10, -2

@@ -9,7 +9,7 @@ corrections would keep an 8x margin under the 1e-3 bar at half the matrix-pipe c
 of f16x3.  Not implemented this round; the operand layout of the scaled
 MFMA was probed in scripts/probe/mx_probe.hip."""
 import importlib, sys, numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 nsg = importlib.import_module('nshogi-engine_amd'); import oracle_lib
 torch.set_num_threads(8)
 def q_f16(t): return t.to(torch.float16).to(torch.float64)
