@@ -1079,7 +1079,7 @@ hipError_t launchConvPrec(const Args& a, int batch, const ConvPlan& p, hipStream
 }
 template <int PREC>
 hipError_t launchHeadsPrec(const Args& a, hipStream_t stream) {
-    constexpr int kMF = 8; // 128 rows per workgroup
+    constexpr int kMF = 2; // 32 rows per one-wave workgroup: ~5 waves per CU hide the per-chunk latencies
     const int gx = (a.totalRows + kMF * 16 - 1) / (kMF * 16);
     return launchOne<PREC, kHeads, kMF, 4, 1>(a, gx, stream);
 }
