@@ -219,10 +219,16 @@ def main():
         mine = selfplay_leg(wpath, local_rank, args.selfplay_seconds, args.selfplay_threads, args.precision,
                             games_per_group=args.selfplay_games_per_group)
         keys = ("games_per_sec", "moves_per_sec", "playouts_per_sec", "evals_per_sec", "games_finished", "concurrent_games")
-        if "error" in mine:
-            sp = mine
+        # every rank takes part in every collective, whether its self-play process failed or not
+        failed = 1.0 if "error" in mine else 0.0
+        if distributed:
+            failed = nsg.dist.sum_over_ranks(failed, device="cuda")
+            tot = {k: nsg.dist.sum_over_ranks(float(mine.get(k, 0.0)), device="cuda") for k in keys}
         else:
-            tot = {k: (nsg.dist.sum_over_ranks(mine[k], device="cuda") if distributed else mine[k]) for k in keys}
+            tot = {k: mine.get(k, 0.0) for k in keys}
+        if failed:
+            sp = {"error": mine.get("error", "the self-play process failed on another rank"), "ranks_failed": int(failed)}
+        else:
             est = (tot["moves_per_sec"] / mine["avg_game_length"]) if mine["avg_game_length"] > 0 else None
             sp = dict(tot, games_per_sec_steady_state_estimate=est, avg_batch=mine["avg_batch"], cache_hit_ratio=mine["cache_hit_ratio"],
                       avg_game_length=mine["avg_game_length"], playouts_per_move=mine["playouts_per_move"],
