@@ -149,6 +149,48 @@ def test_f16m8_small_batches_run_as_f16x3(nsg, oracle):
     check((p[idx], v[idx], d[idx]), net.evaluate(bb[idx]), TOL)
 
 
+def test_f16m8_extreme_magnitudes_stay_finite(nsg, oracle, monkeypatch):
+    """Activations far beyond the fp8 range of the correction operands (BN gamma 512 in the
+    stem: values in the thousands) and weights spanning many binades: the fixed-scale fp8
+    copies saturate instead of overflowing, so outputs stay finite and degrade no further
+    than plain f16 accuracy (the f16 main term is unaffected)."""
+    monkeypatch.setenv("NSG_CONV_NFRAG", "4")
+    w = nsg.weights.make_random(2, 64, seed=22, bn="random")
+    rng = np.random.default_rng(4)
+    w["b0_w1"] = (w["b0_w1"] * np.exp2(rng.integers(-10, 3, size=w["b0_w1"].shape[:1])).reshape(-1, 1, 1, 1)).astype(np.float32)
+    w["stem_bn"][0] *= 512.0
+    blob = nsg.weights.to_blob(w)
+    ev = nsg.Evaluator(0, 8, 86, precision="f16m8")
+    ev.load_memory(blob)
+    bb = nsg.synth.random_batch(8, 86, seed=2)
+    out = ev.compute_blocking(bb)
+    assert ev.last_plan()["trunk_precision"] == "f16m8"
+    ref = oracle.net(blob).evaluate(bb)
+    assert np.isfinite(out[0]).all() and np.isfinite(out[1]).all() and np.isfinite(out[2]).all()
+    scale = max(1.0, float(np.abs(ref[0]).max()))
+    assert float(np.abs(out[0] - ref[0]).max()) <= 2e-2 * scale  # the plain-f16 tolerance of this suite
+    assert float(np.abs(out[1] - ref[1]).max()) <= 2e-2
+
+
+def test_f16m8_chains_bit_identical(nsg, monkeypatch):
+    """More tiles than CUs: two half-batch chains on two streams, bit-identical to one chain."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    batch = 2 * cus + 37
+    bb = nsg.synth.random_batch(batch, 86, seed=78)
+    ev, _ = make(nsg, 2, 256, batch, precision="f16m8", seed=33)
+    p, v, d = ev.compute_blocking(bb)
+    plan = ev.last_plan()
+    assert plan["chains"] == 2 and plan["trunk_precision"] == "f16m8"
+    monkeypatch.setenv("NSG_CHAINS", "1")
+    ev1, _ = make(nsg, 2, 256, batch, precision="f16m8", seed=33)
+    p1, v1, d1 = ev1.compute_blocking(bb)
+    np.testing.assert_array_equal(p, p1)
+    np.testing.assert_array_equal(v, v1)
+    np.testing.assert_array_equal(d, d1)
+
+
 def test_f16m8_full_size_properties(nsg, oracle):
     """kF16m8 at BASELINE's full size (20x256, B=512): a sample of boards against the
     oracle at the north_star tolerance, bit-exact independence from batch composition."""
