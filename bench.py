@@ -294,6 +294,37 @@ def main():
             for _ in range(reps):
                 ev.compute_blocking(bb, policy=pol, win=win, draw=drw)
             out["host_path_evals_per_sec"] = B * reps / (time.perf_counter() - t1)
+            # the same with the legal-move lookup on the device: 80 legal moves per
+            # position, softmax priors returned -- D2H shrinks from 8748 B to 320 B per position
+            rng = np.random.default_rng(1)
+            off = (np.arange(B + 1) * 80).astype(np.uint32)
+            idx = rng.integers(0, 2187, size=B * 80).astype(np.uint16)
+            vals = np.empty(B * 80, np.float32)
+            for _ in range(2):
+                ev.compute_gather_blocking(bb, idx, off, softmax=True, values=vals, win=win, draw=drw)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ev.compute_gather_blocking(bb, idx, off, softmax=True, values=vals, win=win, draw=drw)
+            out["host_path_device_gather_evals_per_sec"] = B * reps / (time.perf_counter() - t1)
+            # the evaluator at the other batch sizes the survey asks for (device-resident)
+            if B == 512 and args.net == "20x256":
+                big = nsg.Evaluator(local_rank, 1024, 86, precision=args.precision)
+                big.load_memory(blob)
+                bbig = nsg.synth.random_batch(1024, 86, seed=nsg.synth.SEED + 1, distinct=True)
+                big.upload_features(bbig)
+                by_batch = {}
+                for nb in (1, 64, 1024):
+                    big.forward_resident(nb)
+                    torch.cuda.synchronize()
+                    k = max(4, min(200, int(20 * 512 / nb) // 8))
+                    t1 = time.perf_counter()
+                    for _ in range(k):
+                        big.forward_resident(nb)
+                    torch.cuda.synchronize()
+                    by_batch[str(nb)] = nb * k / (time.perf_counter() - t1)
+                by_batch["512"] = value
+                out["evals_per_sec_by_batch"] = by_batch
+                big.close()
         if not args.no_host_path and world == 1:
             out["other_precisions_evals_per_sec"] = {
                 p: quick_rate(nsg, local_rank, blob, bb, B, p) for p in ("fp32", "f16x3", "f16m8", "fp16", "bf16")

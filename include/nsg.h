@@ -104,6 +104,28 @@ int nsg_compute_blocking(nsg_evaluator* ev, const void* features,
                          size_t batch_size, float* dst_policy,
                          float* dst_win_rate, float* dst_draw_rate);
 
+/* Extension (no reference counterpart): the evaluation with the
+ * legal-move lookup moved to the device.  The caller sends, per position, the
+ * policy indices of its legal moves -- what FeedWorker::feedResult
+ * (src/mcts/feedworker.cc:120-127) and Frame::setEvaluation
+ * (src/selfplay/frame.cc:105-118) look up one by one in the 2187-wide row -- and
+ * receives only those values: D2H shrinks from 8748 B to ~4 B x legal moves per
+ * position.  move_offsets has batch_size+1 entries (move_offsets[0] = 0, prefix
+ * sums; at most 593 moves per position), move_indices move_offsets[batch_size]
+ * entries in [0, 2187).  With softmax != 0 each position's values are
+ * softmax(logits) (temperature 1, f32), i.e. the priors the host would compute.
+ * dst_values gets move_offsets[batch_size] floats; same one-batch-in-flight and
+ * await() contract as nsg_compute_nonblocking. */
+int nsg_compute_gather_nonblocking(nsg_evaluator* ev, const void* features, size_t batch_size,
+                                   const uint16_t* move_indices, const uint32_t* move_offsets,
+                                   int softmax, float* dst_values, float* dst_win_rate,
+                                   float* dst_draw_rate);
+int nsg_compute_gather_blocking(nsg_evaluator* ev, const void* features, size_t batch_size,
+                                const uint16_t* move_indices, const uint32_t* move_offsets,
+                                int softmax, float* dst_values, float* dst_win_rate,
+                                float* dst_draw_rate);
+#define NSG_MAX_LEGAL_MOVES 593
+
 /* Replaces infer::Infer::await() -- src/infer/infer.h:31, trt.cc:281-283
  * (cudaStreamSynchronize). */
 int nsg_await(nsg_evaluator* ev);

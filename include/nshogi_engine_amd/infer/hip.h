@@ -80,6 +80,18 @@ class Hip : public Infer {
         await();
     }
 
+    // Extension (not part of infer::Infer): the legal-move lookup of
+    // feedworker.cc:120-127 / frame.cc:105-118 on the device.  MoveOffsets: BatchSize+1
+    // prefix sums; MoveIndices: ml::getMoveIndex values; DstValues receives the logits (or,
+    // with Softmax, the priors) of exactly those moves.
+    void computeGatherNonBlocking(const ml::FeatureBitboard* Features, std::size_t BatchSize,
+                                  const uint16_t* MoveIndices, const uint32_t* MoveOffsets,
+                                  bool Softmax, float* DstValues, float* DstWinRate,
+                                  float* DstDrawRate) {
+        check(nsg_compute_gather_nonblocking(Handle, Features, BatchSize, MoveIndices, MoveOffsets,
+                                             Softmax ? 1 : 0, DstValues, DstWinRate, DstDrawRate));
+    }
+
     void await() override {
         check(nsg_await(Handle));
     }

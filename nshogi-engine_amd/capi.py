@@ -95,6 +95,8 @@ def load_library():
     ip = ctypes.POINTER(ctypes.c_int)
     lib.nsg_get_last_plan.argtypes = [vp, ip, ip, ip, ip]
     lib.nsg_get_last_trunk_precision.argtypes = [vp, ip]
+    lib.nsg_compute_gather_blocking.argtypes = [vp, vp, sz, vp, vp, i, vp, vp, vp]
+    lib.nsg_compute_gather_nonblocking.argtypes = [vp, vp, sz, vp, vp, i, vp, vp, vp]
     lib.nsg_cpu_executor_create.argtypes = [i, ctypes.c_uint64, ctypes.POINTER(vp)]
     lib.nsg_cpu_executor_destroy.argtypes = [vp]
     lib.nsg_cpu_executor_compute.argtypes = [vp, vp, sz, vp, vp, vp]
@@ -186,6 +188,24 @@ class Evaluator:
         _check(self._lib.nsg_compute_blocking(self._h, _ptr(a), n, _ptr(policy), _ptr(win),
                                               _ptr(draw)))
         return policy, win, draw
+
+    def compute_gather_blocking(self, features, move_indices, move_offsets, softmax=False,
+                                values=None, win=None, draw=None):
+        """nsg_compute_gather_blocking: only the logits (or softmax priors) of each position's
+        legal moves come back.  move_offsets: batch+1 prefix sums; move_indices: uint16."""
+        a = _features_array(features, self.num_channels)
+        off = np.ascontiguousarray(move_offsets, dtype=np.uint32)
+        idx = np.ascontiguousarray(move_indices, dtype=np.uint16)
+        n = off.shape[0] - 1
+        if values is None:
+            values = np.full((int(off[-1]),), np.nan, dtype=np.float32)
+        if win is None:
+            win = np.full((n,), np.nan, dtype=np.float32)
+        if draw is None:
+            draw = np.full((n,), np.nan, dtype=np.float32)
+        _check(self._lib.nsg_compute_gather_blocking(self._h, _ptr(a), n, _ptr(idx), _ptr(off),
+                                                     1 if softmax else 0, _ptr(values), _ptr(win), _ptr(draw)))
+        return values, win, draw
 
     def await_(self):
         _check(self._lib.nsg_await(self._h))

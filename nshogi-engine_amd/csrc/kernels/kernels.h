@@ -123,6 +123,12 @@ hipError_t launchValueOut(const float* h, const float* w2, const float* b2,
                           float* value, float* draw, int batch, int hidden,
                           hipStream_t stream);
 
+// Legal-move gather: out[offsets[b] + i] = policy[b][idx[offsets[b] + i]],
+// optionally followed by a softmax over each position's moves (what the host does one leaf at
+// a time in feedworker.cc:120-127 / frame.cc:105-118).  One wave per position.
+hipError_t launchGatherLogits(const float* policy, const uint16_t* idx, const uint32_t* offsets,
+                              float* out, int batch, int softmax, hipStream_t stream);
+
 // Fragment-ordered weights: number of 16-byte lane records INCLUDING the eight
 // trailing zero slabs the kernel's prefetch may touch.
 size_t tileWeightRecords(int taps, int kdim, int cout, int prec);

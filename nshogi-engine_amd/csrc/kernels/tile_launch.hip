@@ -214,6 +214,45 @@ hipError_t launchValueOut(const float* h, const float* w2, const float* b2,
     return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void gatherLogitsKernel(
+    const float* __restrict__ policy, const uint16_t* __restrict__ idx,
+    const uint32_t* __restrict__ offsets, float* __restrict__ out, int batch, int softmax) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const uint32_t lo = offsets[b], hi = offsets[b + 1];
+    const float* row = policy + (size_t)b * 2187;
+    if (!softmax) {
+        for (uint32_t i = lo + lane; i < hi; i += 64) out[i] = row[idx[i] < 2187 ? idx[i] : 0];
+        return;
+    }
+    // softmax(T=1) over this position's moves: max, sum of exp, normalise (f32, like the host's)
+    float m = -INFINITY;
+    for (uint32_t i = lo + lane; i < hi; i += 64) m = fmaxf(m, row[idx[i] < 2187 ? idx[i] : 0]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float sum = 0.f;
+    for (uint32_t i = lo + lane; i < hi; i += 64) {
+        const float e = expf(row[idx[i] < 2187 ? idx[i] : 0] - m);
+        out[i] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.0f / sum;
+    for (uint32_t i = lo + lane; i < hi; i += 64) out[i] *= inv;
+}
+} // namespace
+
+hipError_t launchGatherLogits(const float* policy, const uint16_t* idx, const uint32_t* offsets,
+                              float* out, int batch, int softmax, hipStream_t stream) {
+    if (batch <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gatherLogitsKernel, dim3((batch + 3) / 4), dim3(256), 0, stream,
+                       policy, idx, offsets, out, batch, softmax);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // Host-side weight packing.  Record (q, nf, lane) holds, for MFMA row
 // rho = lane & 15 and lane group g = lane >> 4 of output fragment nf:

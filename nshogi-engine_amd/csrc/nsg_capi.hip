@@ -185,6 +185,7 @@ struct nsg_evaluator {
     DevBuf act[3];        // trunk activations [Bpad][81][F] T
     DevBuf policy;        // [B][2187] f32                    (trt.cc:61-62)
     DevBuf value, draw;   // [B] f32                          (trt.cc:63-66)
+    DevBuf moveIdx, moveOff, gathered; // legal-move gather (allocated on first use)
     DevBuf vfeat;         // [B][fc1K] T
     DevBuf hidden;        // [B][VH] f32
     DevBuf scratch;       // debug read-back
@@ -653,6 +654,57 @@ int nsg_compute_nonblocking(nsg_evaluator* ev, const void* features, size_t batc
     NSG_HIP(hipMemcpyAsync(dst_draw_rate, ev->draw.p, batch_size * sizeof(float),
                            hipMemcpyDeviceToHost, ev->stream));
     return NSG_OK;
+}
+
+int nsg_compute_gather_nonblocking(nsg_evaluator* ev, const void* features, size_t batch_size,
+                                   const uint16_t* move_indices, const uint32_t* move_offsets,
+                                   int softmax, float* dst_values, float* dst_win_rate,
+                                   float* dst_draw_rate) {
+    int rc = checkCompute(ev, batch_size);
+    if (rc) return rc;
+    if (!features || !move_indices || !move_offsets || !dst_values || !dst_win_rate || !dst_draw_rate)
+        return fail(NSG_E_INVALID, "null buffer");
+    if (move_offsets[0] != 0) return fail(NSG_E_INVALID, "move_offsets[0] must be 0");
+    for (size_t b = 0; b < batch_size; ++b)
+        if (move_offsets[b + 1] < move_offsets[b] || move_offsets[b + 1] - move_offsets[b] > NSG_MAX_LEGAL_MOVES)
+            return fail(NSG_E_INVALID, "move_offsets must be non-decreasing with at most %d moves per position",
+                        NSG_MAX_LEGAL_MOVES);
+    const size_t total = move_offsets[batch_size];
+    if (hipStreamQuery(ev->stream) == hipErrorNotReady)
+        return fail(NSG_E_BUSY, "compute called while a batch is in flight");
+    if (!ev->moveIdx.p) {
+        const size_t cap = (size_t)ev->batchMax * NSG_MAX_LEGAL_MOVES;
+        if ((rc = ev->moveIdx.alloc(cap * sizeof(uint16_t), false))) return rc;
+        if ((rc = ev->moveOff.alloc(((size_t)ev->batchMax + 1) * sizeof(uint32_t), false))) return rc;
+        if ((rc = ev->gathered.alloc(cap * sizeof(float), false))) return rc;
+    }
+    NSG_HIP(hipMemcpyAsync(ev->input.p, features, batch_size * ev->numChannels * NSG_BITBOARD_BYTES,
+                           hipMemcpyHostToDevice, ev->stream));
+    NSG_HIP(hipMemcpyAsync(ev->moveOff.p, move_offsets, (batch_size + 1) * sizeof(uint32_t),
+                           hipMemcpyHostToDevice, ev->stream));
+    if (total)
+        NSG_HIP(hipMemcpyAsync(ev->moveIdx.p, move_indices, total * sizeof(uint16_t), hipMemcpyHostToDevice,
+                               ev->stream));
+    if ((rc = enqueueForward(ev, batch_size))) return rc;
+    if (total) {
+        NSG_HIP(nsg::launchGatherLogits((const float*)ev->policy.p, (const uint16_t*)ev->moveIdx.p,
+                                        (const uint32_t*)ev->moveOff.p, (float*)ev->gathered.p, (int)batch_size,
+                                        softmax ? 1 : 0, ev->stream));
+        NSG_HIP(hipMemcpyAsync(dst_values, ev->gathered.p, total * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
+    }
+    NSG_HIP(hipMemcpyAsync(dst_win_rate, ev->value.p, batch_size * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
+    NSG_HIP(hipMemcpyAsync(dst_draw_rate, ev->draw.p, batch_size * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
+    return NSG_OK;
+}
+
+int nsg_compute_gather_blocking(nsg_evaluator* ev, const void* features, size_t batch_size,
+                                const uint16_t* move_indices, const uint32_t* move_offsets,
+                                int softmax, float* dst_values, float* dst_win_rate,
+                                float* dst_draw_rate) {
+    int rc = nsg_compute_gather_nonblocking(ev, features, batch_size, move_indices, move_offsets, softmax,
+                                            dst_values, dst_win_rate, dst_draw_rate);
+    if (rc) return rc;
+    return nsg_await(ev);
 }
 
 int nsg_await(nsg_evaluator* ev) {

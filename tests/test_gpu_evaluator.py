@@ -239,6 +239,39 @@ def test_nonblocking_await_contract(nsg, oracle):
     check((pol[:10], win[:10], drw[:10]), (out[0][:10], out[1][:10], out[2][:10]), 1e-5)
 
 
+def test_device_side_legal_move_gather(nsg):
+    """the legal-move lookup on the device.  Gathered logits are bit-identical
+    to indexing the full 2187-wide rows; the device softmax matches the host's f32 softmax;
+    ragged counts including positions with no moves and with the 593-move maximum."""
+    ev, _ = make(nsg, 2, 64, 40, seed=9)
+    bb = nsg.synth.random_batch(40, 86, seed=9)
+    p, v, d = ev.compute_blocking(bb)
+    rng = np.random.default_rng(5)
+    counts = rng.integers(1, 200, size=40)
+    counts[3] = 0
+    counts[7] = 593
+    counts[39] = 1
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    idx = np.concatenate([rng.choice(2187, size=c, replace=False) for c in counts]).astype(np.uint16)
+    g, v2, d2 = ev.compute_gather_blocking(bb, idx, off)
+    want = np.concatenate([p[b, idx[off[b]:off[b + 1]]] for b in range(40)])
+    np.testing.assert_array_equal(g, want)
+    np.testing.assert_array_equal(v2, v)
+    np.testing.assert_array_equal(d2, d)
+    s, _, _ = ev.compute_gather_blocking(bb, idx, off, softmax=True)
+    for b in range(40):
+        row = want[off[b]:off[b + 1]].astype(np.float32)
+        if row.size == 0:
+            continue
+        e = np.exp(row - row.max(), dtype=np.float32)
+        ref = e / e.sum(dtype=np.float32)
+        np.testing.assert_allclose(s[off[b]:off[b + 1]], ref, rtol=2e-6, atol=1e-7)
+        assert abs(float(s[off[b]:off[b + 1]].sum()) - 1.0) < 1e-5
+    bad = off.copy(); bad[5] = bad[6] + 1
+    with pytest.raises(nsg.NsgError):
+        ev.compute_gather_blocking(bb, idx, bad)
+
+
 def test_resident_path_equals_host_path(nsg):
     ev, _ = make(nsg, 2, 64, 16, seed=2)
     bb = nsg.synth.random_batch(16, 86, seed=2)
