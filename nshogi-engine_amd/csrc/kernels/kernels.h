@@ -112,14 +112,19 @@ hipError_t launchHeads(const void* x, const void* wfrag, const float* bias,
                        int coutPadded, int valueChannels, int vfeatStride,
                        float accScale, int prec, hipStream_t stream);
 
-// y[rows][cout] f32 = (ReLU)(x[rows][kdim] T * W + bias): value MLP layer 1.
+// Value MLP layer 1, split over K: y[z][rows][cout] f32 = x[rows][K_z] T * W[K_z] for the
+// denseSplits(kdim, prec) slices K_z of the input channels (a one-wave workgroup walks its
+// chunks serially, one global-load latency each; 9 slices cut that chain 9x: 56 -> 9 us).
+// The partial sums are added in a fixed order, with the bias and the ReLU, by launchValueOut.
+int denseSplits(int kdim, int prec);
 hipError_t launchDense(const void* x, const void* wfrag, const float* bias,
-                       float* y, int rows, int kdim, int cout, int relu,
+                       float* y, int rows, int kdim, int cout, size_t partStride,
                        float accScale, int prec, hipStream_t stream);
 
-// Value MLP layer 2 + squashing: o = w2 h + b2; value = (tanh(o0)+1)/2,
-// draw = sigmoid(o1).  One wave per board, lane-shuffle reduction.
-hipError_t launchValueOut(const float* h, const float* w2, const float* b2,
+// Value MLP layer 1 epilogue (sum of the K slices + b1, ReLU) + layer 2 + squashing:
+// o = w2 h + b2; value = (tanh(o0)+1)/2, draw = sigmoid(o1).  One wave per board.
+hipError_t launchValueOut(const float* h, const float* b1, int nsplit, size_t partStride,
+                          const float* w2, const float* b2,
                           float* value, float* draw, int batch, int hidden,
                           hipStream_t stream);
 

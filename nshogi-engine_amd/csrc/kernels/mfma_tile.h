@@ -161,6 +161,8 @@ struct Args {
     int vfeatStride;          // kHeads: elements per board row of vfeat (>= 81*VC)
     float accScale;           // accumulators are multiplied by this before the bias (kF16x3: 1/weight scale)
     int outF16x3;             // kF16m8: write the kF16x3 layout (last trunk layer, read by the heads)
+    int kSplits;              // kDense: K is split over gridDim.z = kSplits workgroups, each writing its raw
+    size_t partStride;        //   partial sums (no bias, no ReLU) at y + z*partStride floats
     unsigned long long* stamps; // diagnostic builds only (NSG_DIAG_STAMPS): 8 u64 per workgroup
 };
 
@@ -226,7 +228,13 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     const int li = lane & 15;
     const int g = lane >> 4;
     const size_t row0 = (size_t)blockIdx.x * G::kRows;
-    const int nkc = A.kdim * ES / 128;
+    int nkc = A.kdim * ES / 128;
+    int kc0 = 0; // first channel chunk of this workgroup (kDense split-K)
+    if constexpr (MODE == kDense) {
+        const int per = nkc / A.kSplits; // the host picks a divisor
+        kc0 = blockIdx.z * per;
+        nkc = per;
+    }
     const int nft = A.cout / 16;
     const int waveGroup = blockIdx.y * NWAVES + wave; // group of NFRAG fragments
     // kConv buffers are sized for whole workgroups; flat modes clamp rows.
@@ -259,7 +267,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         const int mm = itemOk[k] ? m : 0;
         size_t grow = row0 + mm;
         if (grow > lastRow) grow = lastRow;
-        srcOff[k] = grow * (size_t)A.kdim * ES + c * 16;
+        srcOff[k] = grow * (size_t)A.kdim * ES + c * 16 + (size_t)kc0 * 128;
         // masked lanes store to their own trash slot behind both buffers (one shared slot made
         // every masked store a 64-way same-address conflict that stalled the whole LDS): the store
         // stays unconditional, so st[] stays in registers
@@ -483,7 +491,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     constexpr int kWR = (NFRAG == 1) ? 18 : 6;
     constexpr int kWSets = kWMode == 0 ? kRing : (kWMode == 1 ? 3 : kWR);
     const size_t slabStride = (size_t)nft * 64;
-    const u32x4* wp = A.w + (size_t)waveGroup * NFRAG * 64 + lane;
+    const u32x4* wp = A.w + (size_t)waveGroup * NFRAG * 64 + lane + (size_t)kc0 * (2 * G::kTaps) * slabStride;
     u32x4 w[kWSets][NFRAG];
     constexpr int kLead = kWMode == 0 ? ((kRing == 2) ? 2 : kRing - 1) : (kWMode == 1 ? 2 : kWR - 2); // records requested up front
 #pragma unroll
@@ -974,16 +982,12 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     A.policy[(size_t)b * 2187 + (size_t)(n - vc) * 81 + sq] = v[i];
                 }
             }
-        } else { // kDense: f32 output, bias + optional ReLU
-            if (A.relu) {
-#pragma unroll
-                for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
-            }
-            float* out = reinterpret_cast<float*>(A.y) + grow * (size_t)A.cout + cbase;
+        } else { // kDense: raw f32 partial sums of this K split (bias + ReLU belong to the consumer)
+            float* out = reinterpret_cast<float*>(A.y) + (size_t)blockIdx.z * A.partStride + grow * (size_t)A.cout + cbase;
 #pragma unroll
             for (int j = 0; j < NFRAG; ++j)
                 *reinterpret_cast<f32x4*>(out + j * 4) =
-                    f32x4{v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]};
+                    f32x4{acc[f][j][0] * A.accScale, acc[f][j][1] * A.accScale, acc[f][j][2] * A.accScale, acc[f][j][3] * A.accScale};
         }
     }
 }
@@ -1040,7 +1044,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
             if (err != hipSuccess) return err;
             attrDevMask.fetch_or(1 << dev);
         }
-        hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a);
+        hipLaunchKernelGGL(k, dim3(gridX, gy, MODE == kDense ? a.kSplits : 1), dim3(G::kThreads), G::kLdsAlloc, stream, a);
     }
     return hipGetLastError();
 }

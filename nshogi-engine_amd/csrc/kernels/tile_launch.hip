@@ -150,8 +150,15 @@ hipError_t launchHeads(const void* x, const void* wfrag, const float* bias,
     return hipErrorInvalidValue;
 }
 
+int denseSplits(int kdim, int prec) {
+    const int nkc = kdim / chunkChannels(prec);
+    for (int s = 9; s > 1; --s)
+        if (nkc % s == 0) return s;
+    return 1;
+}
+
 hipError_t launchDense(const void* x, const void* wfrag, const float* bias,
-                       float* y, int rows, int kdim, int cout, int relu,
+                       float* y, int rows, int kdim, int cout, size_t partStride,
                        float accScale, int prec, hipStream_t stream) {
     if (rows <= 0 || (kdim * elemSize(prec)) % 128 != 0 || cout % 64 != 0)
         return hipErrorInvalidValue;
@@ -163,8 +170,10 @@ hipError_t launchDense(const void* x, const void* wfrag, const float* bias,
     a.kdim = kdim;
     a.cout = cout;
     a.totalRows = rows;
-    a.relu = relu;
+    a.relu = 0;
     a.accScale = accScale;
+    a.kSplits = denseSplits(kdim, prec);
+    a.partStride = partStride;
     switch (prec) {
     case kFp32: return tile::launchDenseFp32(a, stream);
     case kFp16: return tile::launchDenseFp16(a, stream);
@@ -179,15 +188,18 @@ hipError_t launchDense(const void* x, const void* wfrag, const float* bias,
 // ---------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void valueOutKernel(
-    const float* __restrict__ h, const float* __restrict__ w2,
-    const float* __restrict__ b2, float* __restrict__ value,
+    const float* __restrict__ h, const float* __restrict__ b1, int nsplit, size_t partStride,
+    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ value,
     float* __restrict__ draw, int batch, int hidden) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= batch) return;
     float s0 = 0.f, s1 = 0.f;
     for (int j = lane; j < hidden; j += 64) {
-        const float hv = h[(size_t)b * hidden + j];
+        // layer 1: the K splits' partial sums in a fixed order, + bias, ReLU
+        float hv = b1[j];
+        for (int z = 0; z < nsplit; ++z) hv += h[(size_t)z * partStride + (size_t)b * hidden + j];
+        hv = fmaxf(hv, 0.f);
         s0 = fmaf(hv, w2[j], s0);
         s1 = fmaf(hv, w2[hidden + j], s1);
     }
@@ -205,12 +217,13 @@ __global__ __launch_bounds__(256) void valueOutKernel(
 }
 } // namespace
 
-hipError_t launchValueOut(const float* h, const float* w2, const float* b2,
+hipError_t launchValueOut(const float* h, const float* b1, int nsplit, size_t partStride,
+                          const float* w2, const float* b2,
                           float* value, float* draw, int batch, int hidden,
                           hipStream_t stream) {
-    if (batch <= 0) return hipErrorInvalidValue;
+    if (batch <= 0 || nsplit < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(valueOutKernel, dim3((batch + 3) / 4), dim3(256), 0, stream,
-                       h, w2, b2, value, draw, batch, hidden);
+                       h, b1, nsplit, partStride, w2, b2, value, draw, batch, hidden);
     return hipGetLastError();
 }
 

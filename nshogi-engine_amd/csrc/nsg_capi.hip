@@ -187,7 +187,7 @@ struct nsg_evaluator {
     DevBuf value, draw;   // [B] f32                          (trt.cc:63-66)
     DevBuf moveIdx, moveOff, gathered; // legal-move gather (allocated on first use)
     DevBuf vfeat;         // [B][fc1K] T
-    DevBuf hidden;        // [B][VH] f32
+    DevBuf hidden;        // [K slices][B][VH] f32 partial sums of the value MLP's first layer
     DevBuf scratch;       // debug read-back
 
     ConvLayer stem;
@@ -342,9 +342,11 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     float* hidden = (float*)ev->hidden.p + (size_t)off * ev->vh;
     NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p, policy, vfeat, count, ev->F,
                              ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, hprec, s));
+    const size_t partStride = (size_t)ev->batchMax * ev->vh; // floats between the K slices' partial sums
     NSG_HIP(nsg::launchDense(vfeat, ev->fc1.w.p, (const float*)ev->fc1.bias.p, hidden, count, ev->fc1K,
-                             ev->vh, 1, ev->fc1.accScale, hprec, s));
-    NSG_HIP(nsg::launchValueOut(hidden, (const float*)ev->fc2W.p, (const float*)ev->fc2B.p,
+                             ev->vh, partStride, ev->fc1.accScale, hprec, s));
+    NSG_HIP(nsg::launchValueOut(hidden, (const float*)ev->fc1.bias.p, nsg::denseSplits(ev->fc1K, hprec), partStride,
+                                (const float*)ev->fc2W.p, (const float*)ev->fc2B.p,
                                 (float*)ev->value.p + off, (float*)ev->draw.p + off, count, ev->vh, s));
     return NSG_OK;
 }
@@ -387,10 +389,12 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         ev->trunkOut = x;
         NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p, (float*)ev->policy.p,
                                  ev->vfeat.p, B, ev->F, ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, prec, s));
+        const size_t partStride = (size_t)ev->batchMax * ev->vh;
         NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->fc1.w.p, (const float*)ev->fc1.bias.p, (float*)ev->hidden.p,
-                                 B, ev->fc1K, ev->vh, 1, ev->fc1.accScale, prec, s));
-        NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->fc2W.p, (const float*)ev->fc2B.p,
-                                    (float*)ev->value.p, (float*)ev->draw.p, B, ev->vh, s));
+                                 B, ev->fc1K, ev->vh, partStride, ev->fc1.accScale, prec, s));
+        NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->fc1.bias.p,
+                                    nsg::denseSplits(ev->fc1K, prec), partStride, (const float*)ev->fc2W.p,
+                                    (const float*)ev->fc2B.p, (float*)ev->value.p, (float*)ev->draw.p, B, ev->vh, s));
     } else if (chains == 1) {
         int rc = enqueueChain(ev, 0, B, plan, s, true, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
         if (rc) return rc;
@@ -580,7 +584,7 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
     for (int i = 0; i < 3; ++i)
         if ((rc = ev->act[i].alloc(bpad * 81 * nv.F * es, true))) return rc;
     if ((rc = ev->vfeat.alloc((size_t)ev->batchMax * ev->fc1K * es, true))) return rc;
-    if ((rc = ev->hidden.alloc((size_t)ev->batchMax * nv.vh * 4, true))) return rc;
+    if ((rc = ev->hidden.alloc((size_t)ev->batchMax * nv.vh * 4 * nsg::denseSplits(ev->fc1K, nsg::headPrecision(prec)), true))) return rc;
     {   // persistent-trunk layer list, same buffer rotation as the per-layer path
         const int nl = 1 + 2 * nv.blocks;
         std::vector<unsigned char> host((size_t)nl * nsg::trunkLayerBytes());
