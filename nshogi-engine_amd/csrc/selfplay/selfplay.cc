@@ -319,6 +319,12 @@ class Game {
             setTerminal(drawValue(S.sideToMove()), 1.0f);
             return false;
         }
+        // checkmate by search (worker.cc:349-358: solver::dfs::solve(State, 3) at every non-root leaf)
+        if (Eng->Opt.MateSearch && Leaf != Root && !S.findMate(3, true, &L).isNone()) {
+            ++Eng->St.MatesFound;
+            setTerminal(1.0f, 0.0f);
+            return false;
+        }
         // expand (Node::expand)
         Leaf->NumChildren = (uint16_t)L.size();
         Leaf->Edges = new Edge[L.size()];

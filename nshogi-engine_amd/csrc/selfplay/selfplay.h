@@ -16,8 +16,9 @@
 //     (the reference seeds from std::random_device, worker.cc:49-50);
 //   * Gumbel mode (worker.cc:428-475 sequential halving, :596-638 transition,
 //     :784-905 sampling / halving schedule) is implemented as in the reference;
-//   * the mate-in-3 dfs / df-pn solver calls (worker.cc:349-358,516-524) are not
-//     implemented: positions are searched instead;
+//   * the mate-in-3 search at leaves (worker.cc:349-358) is shogi::State::findMate(3); the
+//     df-pn solver call in judge (worker.cc:516-524, 100 000 nodes) is not implemented:
+//     the game is simply played on;
 //   * the teacher record writer (saveworker.cc:160-182, libnshogi's SimpleTeacher
 //     format) is out of scope; finished games are only counted.
 // Rules, feature planes and the policy move index come from csrc/shogi (this
@@ -50,6 +51,7 @@ struct Options {
     int MaxPlyMax = 512 + 128;
     bool RandomDrawValue = true; // worker.cc:142-150
     std::size_t EvalCacheEntries = 1 << 15; // per engine; 0 disables
+    bool MateSearch = true;      // mate-in-3 search by checks at every non-root leaf (worker.cc:349-358)
 };
 
 struct Stats {
@@ -58,6 +60,7 @@ struct Stats {
     uint64_t Batches = 0;
     uint64_t Playouts = 0;      // back-propagations (incl. terminal and cached leaves)
     uint64_t Moves = 0;
+    uint64_t MatesFound = 0;    // leaves closed by the mate-in-3 search
     uint64_t GamesBlack = 0, GamesWhite = 0, GamesDraw = 0;
     uint64_t MovesOfFinishedGames = 0;
     uint64_t finished() const { return GamesBlack + GamesWhite + GamesDraw; }

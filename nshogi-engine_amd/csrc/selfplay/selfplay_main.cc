@@ -5,7 +5,7 @@
 //
 // usage: selfplay [--executor hip|random|zero] [--weights file.nsgw] [--gpu 0]
 //                 [--threads 2] [--games-per-group 256] [--playouts 800]
-//                 [--seconds 30] [--max-games 0] [--seed 0] [--precision 3]
+//                 [--seconds 30] [--max-games 0] [--seed 0] [--precision 3] [--mate-search 1]
 #include "selfplay.h"
 
 #include <nshogi_engine_amd/infer/cpu.h>
@@ -42,6 +42,7 @@ int main(int Argc, char* Argv[]) {
         else if (K == "--full-search-ratio") Opt.FullSearchRatio = std::stod(V);
         else if (K == "--cache-entries") Opt.EvalCacheEntries = std::stoull(V);
         else if (K == "--gumbel") Opt.Gumbel = V != "0";
+        else if (K == "--mate-search") Opt.MateSearch = V != "0";
         else if (K == "--num-sampling-moves") Opt.NumSamplingMoves = std::stoi(V);
         else { std::cerr << "unknown option " << K << std::endl; return 2; }
     }
@@ -88,7 +89,7 @@ int main(int Argc, char* Argv[]) {
         S.Evaluations += X.Evaluations; S.CacheHits += X.CacheHits; S.Batches += X.Batches;
         S.Playouts += X.Playouts; S.Moves += X.Moves; S.GamesBlack += X.GamesBlack;
         S.GamesWhite += X.GamesWhite; S.GamesDraw += X.GamesDraw;
-        S.MovesOfFinishedGames += X.MovesOfFinishedGames;
+        S.MovesOfFinishedGames += X.MovesOfFinishedGames; S.MatesFound += X.MatesFound;
         Digest ^= E->moveDigest() * 0x9e3779b97f4a7c15ULL + (uint64_t)(&E - &Engines[0]);
     }
     const double Fin = (double)S.finished();
@@ -102,6 +103,7 @@ int main(int Argc, char* Argv[]) {
               << ", \"playouts_per_sec\": " << S.Playouts / Dt << ", \"evals_per_sec\": " << S.Evaluations / Dt
               << ", \"avg_batch\": " << (S.Batches ? (double)S.Evaluations / S.Batches : 0.0)
               << ", \"cache_hit_ratio\": " << (S.Evaluations + S.CacheHits ? (double)S.CacheHits / (S.Evaluations + S.CacheHits) : 0.0)
+              << ", \"mate_search\": " << (Opt.MateSearch ? 1 : 0) << ", \"mates_found\": " << S.MatesFound
               << ", \"digest\": " << Digest << "}" << std::endl;
     return 0;
 }

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <chrono>
 #include <random>
 #include <string>
 
@@ -37,6 +38,99 @@ int main(int Argc, char** Argv) {
         MoveList L2;
         S.generateLegalMovesSlow(L2);
         std::cout << L.size() << " " << L2.size() << " incheck " << S.inCheck() << " declare " << S.canDeclare() << std::endl;
+        return 0;
+    }
+    if (Cmd == "mate") { // mate <depth> <sfen>: prints the mating move (or "none") with and without the prefilter
+        const int Depth = std::atoi(Argv[2]);
+        State S = State::fromSfen(joinArgs(Argc, Argv, 3));
+        const Move A = S.findMate(Depth, true), B = S.findMate(Depth, false);
+        std::cout << (A.isNone() ? std::string("none") : moveToUsi(A)) << " "
+                  << (B.isNone() ? std::string("none") : moveToUsi(B)) << std::endl;
+        return 0;
+    }
+    if (Cmd == "matecheck") { // matecheck <games> <seed>: prefiltered vs unfiltered search on random playouts
+        const int Games = std::atoi(Argv[2]);
+        std::mt19937_64 Rng((uint64_t)std::atoll(Argv[3]));
+        uint64_t Positions = 0, Mate1 = 0, Mate3 = 0;
+        for (int G = 0; G < Games; ++G) {
+            State S;
+            for (int Ply = 0; Ply < 300; ++Ply) {
+                MoveList L;
+                S.generateLegalMoves(L);
+                if (L.size() == 0 || S.repetitionStatus(true) != NoRepetition) break;
+                const uint64_t H = S.hash();
+                for (const Move& M : L) { // givesCheck vs make-the-move-and-look
+                    const bool Quick = S.givesCheck(M);
+                    S.doMove(M);
+                    const bool Slow = S.inCheck();
+                    S.undoMove();
+                    if (Quick != Slow) { std::cout << "givesCheck mismatch at " << S.toSfen() << " move " << moveToUsi(M) << " quick " << Quick << std::endl; return 1; }
+                }
+                const Move A = S.findMate(3, true), B = S.findMate(3, false);
+                if (S.hash() != H) { std::cout << "findMate changed the position " << S.toSfen() << std::endl; return 1; }
+                if (A.isNone() != B.isNone()) { std::cout << "MISMATCH at " << S.toSfen() << std::endl; return 1; }
+                ++Positions;
+                if (!A.isNone()) {
+                    ++Mate3;
+                    if (!S.findMate(1, true).isNone()) ++Mate1;
+                    // verify: after A the defender is in check and every reply allows a mate in one
+                    S.doMove(A);
+                    if (!S.inCheck()) { std::cout << "mating move gives no check " << S.toSfen() << std::endl; return 1; }
+                    MoveList R;
+                    S.generateLegalMoves(R);
+                    for (const Move& Rm : R) {
+                        S.doMove(Rm);
+                        if (S.findMate(1, false).isNone()) { std::cout << "reply escapes " << S.toSfen() << std::endl; return 1; }
+                        S.undoMove();
+                    }
+                    S.undoMove();
+                }
+                S.doMove(L[(int)(Rng() % (uint64_t)L.size())]);
+            }
+        }
+        std::cout << "positions " << Positions << " mate3 " << Mate3 << " mate1 " << Mate1 << " ok" << std::endl;
+        return 0;
+    }
+    if (Cmd == "matesample") { // matesample <seed>: a random-playout position with a mate in three but not in one
+        std::mt19937_64 Rng((uint64_t)std::atoll(Argv[2]));
+        for (int G = 0; G < 1000; ++G) {
+            State S;
+            for (int Ply = 0; Ply < 200; ++Ply) {
+                MoveList L;
+                S.generateLegalMoves(L);
+                if (L.size() == 0 || S.repetitionStatus(true) != NoRepetition) break;
+                if (S.findMate(1).isNone() && !S.findMate(3).isNone()) {
+                    std::cout << S.toSfen() << std::endl;
+                    return 0;
+                }
+                S.doMove(L[(int)(Rng() % (uint64_t)L.size())]);
+            }
+        }
+        return 1;
+    }
+    if (Cmd == "matebench") { // matebench <games> <seed>: ns per findMate(3) and per generateLegalMoves on random playouts
+        const int Games = std::atoi(Argv[2]);
+        std::mt19937_64 Rng((uint64_t)std::atoll(Argv[3]));
+        std::vector<State> Pos;
+        for (int G = 0; G < Games; ++G) {
+            State S;
+            for (int Ply = 0; Ply < 200; ++Ply) {
+                MoveList L;
+                S.generateLegalMoves(L);
+                if (L.size() == 0 || S.repetitionStatus(true) != NoRepetition) break;
+                Pos.push_back(S);
+                S.doMove(L[(int)(Rng() % (uint64_t)L.size())]);
+            }
+        }
+        auto T0 = std::chrono::steady_clock::now();
+        uint64_t Found = 0, Total = 0;
+        for (State& S : Pos) Found += !S.findMate(3).isNone();
+        auto T1 = std::chrono::steady_clock::now();
+        for (State& S : Pos) { MoveList L; S.generateLegalMoves(L); Total += L.size(); }
+        auto T2 = std::chrono::steady_clock::now();
+        std::cout << "positions " << Pos.size() << " mates " << Found << " findMate(3) "
+                  << std::chrono::duration<double, std::nano>(T1 - T0).count() / Pos.size() << " ns, generateLegalMoves "
+                  << std::chrono::duration<double, std::nano>(T2 - T1).count() / Pos.size() << " ns (" << (double)Total / Pos.size() << " moves)" << std::endl;
         return 0;
     }
     if (Cmd == "moves") {

@@ -579,6 +579,118 @@ bool State::canDeclare() const {
     return Points >= (Us == Black ? 28 : 27);
 }
 
+namespace {
+inline int sgn(int V) { return (V > 0) - (V < 0); }
+inline int dirIndex(int SF, int SR) {
+    for (int D = 0; D < 8; ++D)
+        if (kDF[D] == SF && kDR[D] == SR) return D;
+    return -1;
+}
+inline bool onLine(int DF, int DR) { return (DF || DR) && (DF == 0 || DR == 0 || DF == DR || DF == -DR); }
+} // namespace
+
+bool State::givesCheck(Move M) const {
+    const Color Us = Side;
+    const int K = KingSq[~Us], KF = fileOf(K), KR = rankOf(K);
+    const int To = M.to(), TF = fileOf(To), TR = rankOf(To);
+    const PieceType T = M.promote() ? promote(M.moved()) : M.moved();
+    const Piece P = makePiece(Us, T);
+    const int From = M.isDrop() ? -1 : M.from();
+    // ---- direct: the piece as it stands on To attacks the king
+    if (T == Knight) {
+        if (KR - TR == 2 * forward(Us) && (KF - TF == 1 || KF - TF == -1)) return true;
+    } else {
+        const int DF = KF - TF, DR = KR - TR;
+        if (onLine(DF, DR)) {
+            const int SF = sgn(DF), SR = sgn(DR);
+            const uint8_t Bit = (uint8_t)(1u << dirIndex(SF, SR));
+            const int Dist = DF ? (DF < 0 ? -DF : DF) : (DR < 0 ? -DR : DR);
+            if (Dist == 1 && (stepMask(P) & Bit)) return true;
+            if (slideMask(P) & Bit) {
+                bool Clear = true;
+                for (int F = TF + SF, R = TR + SR; F != KF || R != KR; F += SF, R += SR) {
+                    const int S2 = makeSquare(F, R);
+                    if (S2 != From && Board[S2]) {
+                        Clear = false;
+                        break;
+                    }
+                }
+                if (Clear) return true;
+            }
+        }
+    }
+    // ---- discovered: From leaves a line between the king and one of our sliders
+    if (From >= 0) {
+        const int DF = fileOf(From) - KF, DR = rankOf(From) - KR;
+        if (onLine(DF, DR)) {
+            const int SF = sgn(DF), SR = sgn(DR);
+            const int TDF = TF - KF, TDR = TR - KR;
+            const bool StaysOnRay = onLine(TDF, TDR) && sgn(TDF) == SF && sgn(TDR) == SR;
+            if (!StaysOnRay) {
+                int F = KF + SF, R = KR + SR;
+                bool Clear = true;
+                for (; makeSquare(F, R) != From; F += SF, R += SR)
+                    if (Board[makeSquare(F, R)]) {
+                        Clear = false;
+                        break;
+                    }
+                if (Clear) {
+                    const uint8_t Back = (uint8_t)(1u << ((dirIndex(SF, SR) + 4) & 7)); // from the slider toward the king
+                    for (F += SF, R += SR; onBoard(F, R); F += SF, R += SR) {
+                        const Piece Q = Board[makeSquare(F, R)];
+                        if (!Q) continue;
+                        if (colorOf(Q) == Us && (slideMask(Q) & Back)) return true;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    return false;
+}
+
+Move State::findMate(int Depth, bool Prefilter, const MoveList* Legal) {
+    if (Depth < 1) return Move();
+    MoveList Own;
+    if (!Legal) generateLegalMoves(Own);
+    const MoveList& Moves = Legal ? *Legal : Own;
+    // checking moves first pass: mate in one; second pass (Depth >= 3): every reply refuted
+    Move Checks[600];
+    int NumChecks = 0;
+    for (const Move& M : Moves) {
+        if (Prefilter && !givesCheck(M)) continue;
+        doMove(M);
+        if (!inCheck()) { // (after the move the side to move is the defender; only reached without the prefilter)
+            undoMove();
+            continue;
+        }
+        MoveList Replies;
+        generateLegalMoves(Replies);
+        undoMove();
+        if (Replies.size() == 0) return M; // drop-pawn mate is not a legal move, so M is a real mate
+        Checks[NumChecks++] = M;
+    }
+    if (Depth < 3) return Move();
+    for (int I = 0; I < NumChecks; ++I) {
+        doMove(Checks[I]);
+        MoveList Replies;
+        generateLegalMoves(Replies);
+        bool AllMated = true;
+        for (const Move& R : Replies) {
+            doMove(R);
+            const bool Mated = !findMate(1, Prefilter).isNone();
+            undoMove();
+            if (!Mated) {
+                AllMated = false;
+                break;
+            }
+        }
+        undoMove();
+        if (AllMated) return Checks[I];
+    }
+    return Move();
+}
+
 uint64_t State::perft(int Depth) {
     MoveList L;
     generateLegalMoves(L);

@@ -122,6 +122,15 @@ class State {
 
     Move moveFrom16(uint16_t M16) const; // rebuild moved/captured from the position
 
+    // Forced-mate search by checks only (role of libnshogi's solver::dfs::solve(State, 3) at
+    // selfplay/worker.cc:349-358): a move of the side to move that checkmates within Depth
+    // plies (1 or 3) against every defence, or a none move.  Prefilter = false tests every
+    // legal move for check (slow reference for the tests).
+    Move findMate(int Depth, bool Prefilter = true, const MoveList* Legal = nullptr); // Legal: the position's legal moves, if already generated
+    // Does this legal move of the side to move give check (directly or by discovery)?  Exact,
+    // from the current position, without making the move.
+    bool givesCheck(Move M) const;
+
     uint64_t perft(int Depth);
 
  private:

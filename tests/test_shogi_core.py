@@ -67,6 +67,26 @@ def test_generators_agree_on_random_playouts():
     assert out.startswith("ok positions")
 
 
+def test_mate_search_known_positions():
+    """findMate (role of solver::dfs::solve(State, 3), selfplay/worker.cc:349-358)."""
+    # gold drop / gold move mates a cornered king in one
+    a, b = run("perft", "mate", 1, "8k/9/7GG/9/9/9/9/9/K8 b - 1").split()
+    assert a != "none" and b != "none"
+    # the same king with no attackers nearby: no mate within three plies
+    assert run("perft", "mate", 3, "8k/9/9/9/9/9/9/9/K7G b - 1").split() == ["none", "none"]
+    # a random-playout position (perft matesample 4) with a mate in three but not in one
+    sfen = "l2k5/4s2r1/P1p1l3G/1p3g1pP/LbPp5/1N1P1sP1p/+n+r1gP+p1PS/6pBL/+n3SK2G w 2Pn2p 182"
+    assert run("perft", "mate", 1, sfen).split() == ["none", "none"]
+    assert run("perft", "mate", 3, sfen).split() == ["6g5h", "6g5h"]
+
+
+def test_mate_search_agrees_with_exhaustive_on_random_playouts():
+    """givesCheck vs make-the-move-and-look for every legal move, the check-prefiltered
+    search vs the unfiltered one, and every found mate verified against every defence."""
+    out = run("perft", "matecheck", 80, 13)
+    assert out.strip().endswith("ok") and "mate3" in out
+
+
 def test_selfplay_cpu_random_executor_reproducible():
     """EXECUTOR=random self-play (BASELINE config 1 plumbing): finishes games and is
     bit-reproducible under a fixed seed; a different seed plays different games."""
