@@ -530,9 +530,16 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     constexpr bool kSlot = kSlotR > 0;
     static_assert(!kFlow || kSlot || kSlabs % kRingA == 0, "ring slot must carry across chunks");
     static_assert(!kSlot || (2 * G::kTaps) % kSlotR == 0, "fragment sets must carry across chunks");
-    constexpr int kWriteSlab = kSlot ? 3 * (G::kTaps / 3) + 1 : kSlabs / 3;
     // barrier at the top of the first slab that reads the next chunk's buffer
     constexpr int kBarSlab = kSlot ? (kSlotR == 2 ? kSlabs - 1 : kSlabs - 3) : kSlabs - kRingA + 1;
+    // Next chunk's tile: its items are requested one per slab over the first slabs, each
+    // BEHIND that slab's weight request (VMEM returns in order: a weight record queued
+    // behind the lock-step tile burst waits an HBM round trip with it), and written to
+    // LDS in the slab before the barrier.
+    constexpr int kLoadSlabs = G::kItems < 6 ? G::kItems : 6;
+    constexpr int kItemsPerSlab = (G::kItems + kLoadSlabs - 1) / kLoadSlabs;
+    constexpr int kWriteSlab = kBarSlab - 1;
+    static_assert(!kFlow || kLoadSlabs + 2 < kWriteSlab, "tile staging order");
     if constexpr (kFlow) {
 #pragma unroll
         for (int q = 0; q < (kSlot ? kSlotR - 1 : kRingA - 1); ++q)
@@ -550,9 +557,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 for (int f = 0; f < G::kMF; ++f)
                     if (q < kSlabs) a[q][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + slabOff(q));
         }
-        // next chunk's tile: global -> registers now, registers -> LDS later
+        // next chunk's tile: global -> registers, registers -> LDS later
         // (the last iteration re-loads its own chunk: harmless, keeps st[] in registers)
-        NSG_STAGE_LOAD(kc + 1 < nkc ? kc + 1 : kc)
+        if constexpr (!kFlow) { NSG_STAGE_LOAD(kc + 1 < nkc ? kc + 1 : kc) }
 #pragma unroll
         for (int s = 0; s < kSlabs; ++s) {
             if constexpr (kFlow) {
@@ -614,6 +621,13 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     wp += slabStride;
                 }
             }
+            if constexpr (kFlow) {
+                if (s < kLoadSlabs) {
+#pragma unroll
+                    for (int k = s; k < G::kItems; k += kLoadSlabs)
+                        st[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)(kc + 1 < nkc ? kc + 1 : kc) * 128);
+                }
+            }
             // -- this slab's MFMAs
             const int aslot = kSlot ? (2 * (s / 3) + (s % 3 == 2 ? 1 : 0)) % kSlotR : s % kRingA;
 #pragma unroll
@@ -633,6 +647,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 for (int f = 0; f < G::kMF; ++f) {
                     if (dsReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
                     if (wLoads && f < NFRAG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
+                    if (kFlow && s < kLoadSlabs && f == NFRAG) __builtin_amdgcn_sched_group_barrier(0x020, kItemsPerSlab, 0); // tile items
                     if (kFlow && s == kWriteSlab && f < G::kItems)
                         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); // DS write
                     __builtin_amdgcn_sched_group_barrier(0x008, NFRAG * kMfmaPerPair, 0); // MFMA
