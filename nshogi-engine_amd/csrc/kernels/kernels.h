@@ -98,7 +98,7 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
 size_t trunkLayerBytes();
 void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfrag,
                     const float* bias, const void* residual, void* y, int cin,
-                    int cout, int relu, float accScale);
+                    int cout, int relu, float accScale, bool outF16x3 = false);
 bool canRunTrunk(int cout, const ConvPlan& plan);
 hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
                        const ConvPlan& plan, hipStream_t stream);

@@ -222,7 +222,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     static_assert(!kM8 || (MODE == kConv && NFRAG == 4), "kF16m8: full trunk-conv tiles only");
     static_assert(NFRAG == 1 || NFRAG == 2 || NFRAG == 4, "fragments per wave");
 
-    const int tid = threadIdx.x;
+    int tidOpaque = threadIdx.x;
+    // (opaque to the optimiser: inside the persistent trunk kernel the per-lane address tables
+    // below would otherwise be hoisted out of the layer loop and stay live through the epilogue)
+    asm volatile("" : "+v"(tidOpaque));
+    const int tid = tidOpaque;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15;
@@ -1020,12 +1024,21 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, N
 // boundary between layers.  Workgroups drift apart freely instead of being
 // re-synchronised 2N+1 times per forward.
 template <int PREC, int SIZE, int NFRAG, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES>())) void trunkKernel(
-    const Args* __restrict__ layers, int nLayers) {
+__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, NFRAG, PREC>())) void trunkKernel(
+    const Args* __restrict__ layers, int nLayers, int skewTicks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (skewTicks > 0) {
+        // deliberate phase shift between workgroups (units of the 100 MHz constant clock): their HBM
+        // bursts (tile loads, epilogue) then fall into each other's matrix phases
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)skewTicks * ((blockIdx.x >> 3) & 7);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     for (int l = 0; l < nLayers; ++l) {
         const Args A = layers[l];
-        tileBody<PREC, kConv, SIZE, NFRAG, NWAVES, 2>(A, smem, true); // the epilogue staging reuses the halo entries: re-zero
+        // (two instantiations rather than a run-time residual flag: the merged body spills)
+        if (A.res) tileBody<PREC, kConv, SIZE, NFRAG, NWAVES, 1>(A, smem, true); // the epilogue staging reuses the halo entries: re-zero
+        else tileBody<PREC, kConv, SIZE, NFRAG, NWAVES, 0>(A, smem, true);
         // this layer's stores (all waves) land before any wave stages them as the
         // next layer's input: vmcnt(0) + workgroup barrier (same CU, same L1/L2 path)
         __syncthreads();
@@ -1070,7 +1083,8 @@ hipError_t launchTrunkOne(const Args* layers, int nLayers, int gridX, hipStream_
     auto k = trunkKernel<PREC, SIZE, NFRAG, NWAVES>;
     hipError_t err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k, dim3(gridX, 1), dim3(G::kThreads), G::kLdsAlloc, stream, layers, nLayers);
+    static const int skew = [] { const char* e = getenv("NSG_TRUNK_SKEW_US"); return e ? atoi(e) * 100 : 0; }();
+    hipLaunchKernelGGL(k, dim3(gridX, 1), dim3(G::kThreads), G::kLdsAlloc, stream, layers, nLayers, skew);
     return hipGetLastError();
 }
 
@@ -1120,6 +1134,7 @@ hipError_t launchDenseFp16(const Args& a, hipStream_t s);
 hipError_t launchDenseBf16(const Args& a, hipStream_t s);
 hipError_t launchConvF16x3(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchTrunkF16m8(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkFp32(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkFp16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkBf16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);

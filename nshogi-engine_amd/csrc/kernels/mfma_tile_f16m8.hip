@@ -16,5 +16,14 @@ hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStrea
     return hipErrorInvalidValue;
 }
 
+hipError_t launchTrunkF16m8(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s) {
+    const int gx = (batch + p.nb - 1) / p.nb;
+    if (p.nfrag == 4 && p.nb == 2 && p.nwaves == 4) return launchTrunkOne<kF16m8, 2, 4, 4>(layers, n, gx, s);
+    if (p.nfrag == 4 && p.nb == 1 && p.nwaves == 4) return launchTrunkOne<kF16m8, 1, 4, 4>(layers, n, gx, s);
+    if (p.nfrag == 4 && p.nb == 2 && p.nwaves == 3) return launchTrunkOne<kF16m8, 2, 4, 3>(layers, n, gx, s);
+    if (p.nfrag == 4 && p.nb == 1 && p.nwaves == 3) return launchTrunkOne<kF16m8, 1, 4, 3>(layers, n, gx, s);
+    return hipErrorInvalidValue;
+}
+
 } // namespace tile
 } // namespace nsg

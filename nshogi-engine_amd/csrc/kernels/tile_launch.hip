@@ -91,8 +91,9 @@ size_t trunkLayerBytes() { return sizeof(tile::Args); }
 
 void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfrag,
                     const float* bias, const void* residual, void* y, int cin,
-                    int cout, int relu, float accScale) {
+                    int cout, int relu, float accScale, bool outF16x3) {
     tile::Args a{};
+    a.outF16x3 = outF16x3 ? 1 : 0;
     a.x = (const unsigned char*)x;
     a.w = (const tile::u32x4*)wfrag;
     a.bias = bias;
@@ -118,6 +119,7 @@ hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
     case kFp16: return tile::launchTrunkFp16(L, nLayers, batch, plan, stream);
     case kBf16: return tile::launchTrunkBf16(L, nLayers, batch, plan, stream);
     case kF16x3: return tile::launchTrunkF16x3(L, nLayers, batch, plan, stream);
+    case kF16m8: return tile::launchTrunkF16m8(L, nLayers, batch, plan, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -387,13 +387,14 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         if (prof) NSG_HIP(hipEventRecord(e[2], s));
         void* x = (ev->blocks % 2 == 1) ? ev->act[2].p : ev->act[0].p;
         ev->trunkOut = x;
+        ev->lastTrunkPrec = prec;
         NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p, (float*)ev->policy.p,
-                                 ev->vfeat.p, B, ev->F, ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, prec, s));
+                                 ev->vfeat.p, B, ev->F, ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, nsg::headPrecision(prec), s));
         const size_t partStride = (size_t)ev->batchMax * ev->vh;
         NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->fc1.w.p, (const float*)ev->fc1.bias.p, (float*)ev->hidden.p,
-                                 B, ev->fc1K, ev->vh, partStride, ev->fc1.accScale, prec, s));
+                                 B, ev->fc1K, ev->vh, partStride, ev->fc1.accScale, nsg::headPrecision(prec), s));
         NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->fc1.bias.p,
-                                    nsg::denseSplits(ev->fc1K, prec), partStride, (const float*)ev->fc2W.p,
+                                    nsg::denseSplits(ev->fc1K, nsg::headPrecision(prec)), partStride, (const float*)ev->fc2W.p,
                                     (const float*)ev->fc2B.p, (float*)ev->value.p, (float*)ev->draw.p, B, ev->vh, s));
     } else if (chains == 1) {
         int rc = enqueueChain(ev, 0, B, plan, s, true, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
@@ -595,14 +596,15 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
             nsg::fillTrunkLayer(host.data(), 1 + 2 * k, x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p,
                                 nullptr, y, nv.F, nv.F, 1, ev->conv1[k].accScale);
             nsg::fillTrunkLayer(host.data(), 2 + 2 * k, y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p,
-                                x, z, nv.F, nv.F, 1, ev->conv2[k].accScale);
+                                x, z, nv.F, nv.F, 1, ev->conv2[k].accScale,
+                                prec == nsg::kF16m8 && k == nv.blocks - 1);
             void* t = x; x = z; z = t;
         }
         if ((rc = ev->trunkLayers.alloc(host.size(), false))) return rc;
         NSG_HIP(hipMemcpy(ev->trunkLayers.p, host.data(), host.size(), hipMemcpyHostToDevice));
         ev->trunkLayerCount = nl;
         const char* env = getenv("NSG_TRUNK_KERNEL");
-        ev->useTrunkKernel = (env && env[0] == '1') && prec != nsg::kF16m8;
+        ev->useTrunkKernel = (env && env[0] == '1');
     }
     NSG_HIP(hipDeviceSynchronize());
     ev->loaded = true;

@@ -172,6 +172,21 @@ def test_f16m8_extreme_magnitudes_stay_finite(nsg, oracle, monkeypatch):
     assert float(np.abs(out[1] - ref[1]).max()) <= 2e-2
 
 
+def test_f16m8_persistent_trunk_kernel_bit_identical(nsg, monkeypatch):
+    """NSG_TRUNK_KERNEL=1: all 3x3 layers in one launch (a workgroup owns its boards through
+    every layer, no grid barrier).  Same arithmetic, so bit-identical to per-layer launches."""
+    bb = nsg.synth.random_batch(300, 86, seed=79)
+    ev, _ = make(nsg, 3, 256, 300, precision="f16m8", seed=34)
+    p, v, d = ev.compute_blocking(bb)
+    monkeypatch.setenv("NSG_TRUNK_KERNEL", "1")
+    ev1, _ = make(nsg, 3, 256, 300, precision="f16m8", seed=34)
+    p1, v1, d1 = ev1.compute_blocking(bb)
+    assert ev1.last_plan()["trunk_precision"] == "f16m8"
+    np.testing.assert_array_equal(p, p1)
+    np.testing.assert_array_equal(v, v1)
+    np.testing.assert_array_equal(d, d1)
+
+
 def test_f16m8_chains_bit_identical(nsg, monkeypatch):
     """More tiles than CUs: two half-batch chains on two streams, bit-identical to one chain."""
     probe = nsg.Evaluator(0, 1, 86)
