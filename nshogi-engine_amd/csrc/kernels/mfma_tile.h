@@ -71,7 +71,11 @@ struct Geom {
     static constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
     static constexpr int kBuf = 8 * kPlane;  // one 128-byte channel chunk
     static constexpr int kLds = 2 * kBuf;    // double buffered
-    static constexpr int kLdsAlloc = kLds + 1024; // + one trash slot per lane for masked staging lanes
+    // LDS the epilogue may stage through: a two-board tile has the CU to itself (its waves need the
+    // whole register file), so it takes the whole 160 KiB and moves 9 of its 11 fragments per batch --
+    // the residual loads of a batch are one global round trip, and batches run back to back.
+    static constexpr int kEpi = kLds; // (the whole 160 KiB = 9 fragments per batch was 3 % slower: fewer, longer batches overlap less)
+    static constexpr int kLdsAlloc = (kEpi > kLds ? kEpi : kLds) + 1024; // + one trash slot per lane for masked staging lanes
     static constexpr int kThreads = NWAVES * 64;
     static constexpr int kItems = (2 * kMF + NWAVES - 1) / NWAVES;
     static constexpr int kTaps = kBoards ? 9 : 1;
@@ -782,10 +786,13 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         constexpr int kRPI = 64 / kPPR;             // rows per wave instruction: 4 or 8
         constexpr int kIPF = 16 / kRPI;             // instructions per 16-row fragment
         constexpr int kFragBytes = 16 * kRowS;
-        constexpr int kFPB = (G::kLds / NWAVES / kFragBytes) < 1 ? 1
-                           : ((G::kLds / NWAVES / kFragBytes) > G::kMF ? G::kMF : (G::kLds / NWAVES / kFragBytes));
-        static_assert(kFragBytes <= G::kLds / NWAVES, "epilogue staging does not fit");
-        unsigned char* ebuf = smem + wave * (G::kLds / NWAVES);
+        constexpr int kEpiWave = G::kEpi / NWAVES / 16 * 16;
+        // fragments per batch: one.  (Three -- what the image's LDS holds per wave -- was 1 % slower,
+        // nine with the whole 160 KiB 3 % slower: short batches let stores and loads of neighbouring
+        // fragments overlap.)
+        constexpr int kFPB = 1;
+        static_assert(kFragBytes <= kEpiWave, "epilogue staging does not fit");
+        unsigned char* ebuf = smem + wave * kEpiWave;
         const size_t rowBytes = (size_t)A.cout * ES;
         const size_t sliceOff = (size_t)waveGroup * kRowB;
         // byte offset, inside the row slice, of this lane's k-th 16-byte piece
@@ -804,6 +811,23 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         const int lrow = lane / kPPR;   // lane-linear view: row within an instruction
         const int lpc = lane % kPPR;    //                   piece within the row
 
+        // The whole residual slice of this wave is requested up front (the main loop's operand
+        // registers are dead: kMF x kIPF 16-byte pieces per lane), so the fragment batches below
+        // never wait a global round trip each.
+        constexpr bool kPreRes = (RES == 1) && (G::kMF * kIPF <= 48);
+        u32x4 rpre[kPreRes ? G::kMF : 1][kIPF];
+        if constexpr (kPreRes) {
+#pragma unroll
+            for (int f = 0; f < G::kMF; ++f)
+#pragma unroll
+                for (int it = 0; it < kIPF; ++it) {
+                    const int m = f * 16 + it * kRPI + lrow;
+                    rpre[f][it] = u32x4{0u, 0u, 0u, 0u};
+                    if (m < G::kRows)
+                        rpre[f][it] = *reinterpret_cast<const u32x4*>(A.res + (row0 + m) * rowBytes + sliceOff + lpc * 16);
+                }
+        }
+
 #pragma unroll
         for (int f0 = 0; f0 < G::kMF; f0 += kFPB) {
             if (hasRes) {
@@ -816,8 +840,12 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                             const int r = it * kRPI + lrow;
                             const int m = (f0 + ff) * 16 + r;
                             u32x4 t = u32x4{0u, 0u, 0u, 0u};
-                            if (m < G::kRows)
-                                t = *reinterpret_cast<const u32x4*>(A.res + (row0 + m) * rowBytes + sliceOff + lpc * 16);
+                            if constexpr (kPreRes) {
+                                t = rpre[f0 + ff][it];
+                            } else {
+                                if (m < G::kRows)
+                                    t = *reinterpret_cast<const u32x4*>(A.res + (row0 + m) * rowBytes + sliceOff + lpc * 16);
+                            }
                             *reinterpret_cast<u32x4*>(ebuf + ff * kFragBytes + r * kRowS + lpc * 16) = t;
                         }
                     }
