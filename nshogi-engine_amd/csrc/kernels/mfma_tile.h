@@ -787,10 +787,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         constexpr int kIPF = 16 / kRPI;             // instructions per 16-row fragment
         constexpr int kFragBytes = 16 * kRowS;
         constexpr int kEpiWave = G::kEpi / NWAVES / 16 * 16;
-        // fragments per batch: one.  (Three -- what the image's LDS holds per wave -- was 1 % slower,
-        // nine with the whole 160 KiB 3 % slower: short batches let stores and loads of neighbouring
-        // fragments overlap.)
-        constexpr int kFPB = 1;
+        // staging regions per wave (one fragment each).  (Batches of three fragments were 1 % slower than
+        // one at a time, batches of nine through the whole 160 KiB 3 % slower.)
+        constexpr int kRegions = (kEpiWave / kFragBytes) < 1 ? 1 : ((kEpiWave / kFragBytes) > 4 ? 4 : (kEpiWave / kFragBytes));
         static_assert(kFragBytes <= kEpiWave, "epilogue staging does not fit");
         unsigned char* ebuf = smem + wave * kEpiWave;
         const size_t rowBytes = (size_t)A.cout * ES;
@@ -811,14 +810,16 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         const int lrow = lane / kPPR;   // lane-linear view: row within an instruction
         const int lpc = lane % kPPR;    //                   piece within the row
 
-        // The whole residual slice of this wave is requested up front (the main loop's operand
-        // registers are dead: kMF x kIPF 16-byte pieces per lane), so the fragment batches below
-        // never wait a global round trip each.
-        constexpr bool kPreRes = (RES == 1) && (G::kMF * kIPF <= 48);
-        u32x4 rpre[kPreRes ? G::kMF : 1][kIPF];
-        if constexpr (kPreRes) {
+        // Most of this wave's residual slice is requested up front (the main loop's operand registers
+        // are dead), so the fragment pipeline below does not wait a global round trip per fragment.
+        // (only the first kPreFrags fragments: with all eleven the epilogue spills; kernels capped at
+        // 256 registers for two waves per SIMD request every fragment one pipeline stage ahead instead)
+        constexpr int kPreFrags = (RES != 1 || minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG, PREC>() > 1)
+                                      ? 0 : (G::kMF * kIPF <= 32 ? G::kMF : 32 / kIPF);
+        u32x4 rpre[kPreFrags ? kPreFrags : 1][kIPF];
+        if constexpr (kPreFrags > 0) {
 #pragma unroll
-            for (int f = 0; f < G::kMF; ++f)
+            for (int f = 0; f < kPreFrags; ++f)
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
                     const int m = f * 16 + it * kRPI + lrow;
@@ -828,92 +829,115 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 }
         }
 
+        // Three stages per fragment, software-pipelined over the fragments so that no stage waits for
+        // the LDS round trip of the one before it:
+        //   R(f): residual pieces -> LDS image (lane-linear rows) -> this lane's MFMA-layout pieces
+        //   X(f): bias, residual, ReLU, conversions; result pieces -> LDS image
+        //   S(f): LDS image -> global, lane-linear rows
+        // Iteration i issues S's reads for fragment i-1, R(i+1), X(i), then S's stores for i-1.  LDS
+        // executes a wave's operations in order, so two staging regions suffice: the reads of
+        // fragment i-1 are issued before R(i+1) overwrites their region.
+        static_assert(kRegions >= 2, "the pipelined epilogue needs two staging regions per wave");
+        u32x4 rpp[2][kNP];
+        u32x4 tt[kIPF];
 #pragma unroll
-        for (int f0 = 0; f0 < G::kMF; f0 += kFPB) {
-            if (hasRes) {
-                // residual: global (lane-linear, full lines) -> LDS image
+        for (int i = -1; i <= G::kMF; ++i) {
+            if (i >= 1) { // ---- S(i-1), reads
+                const int f = i - 1;
 #pragma unroll
-                for (int ff = 0; ff < kFPB; ++ff) {
-                    if (f0 + ff < G::kMF) {
-#pragma unroll
-                        for (int it = 0; it < kIPF; ++it) {
-                            const int r = it * kRPI + lrow;
-                            const int m = (f0 + ff) * 16 + r;
-                            u32x4 t = u32x4{0u, 0u, 0u, 0u};
-                            if constexpr (kPreRes) {
-                                t = rpre[f0 + ff][it];
-                            } else {
-                                if (m < G::kRows)
-                                    t = *reinterpret_cast<const u32x4*>(A.res + (row0 + m) * rowBytes + sliceOff + lpc * 16);
-                            }
-                            *reinterpret_cast<u32x4*>(ebuf + ff * kFragBytes + r * kRowS + lpc * 16) = t;
-                        }
-                    }
-                }
+                for (int it = 0; it < kIPF; ++it)
+                    tt[it] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + (it * kRPI + lrow) * kRowS + lpc * 16);
             }
+            if (hasRes && i + 1 < G::kMF) { // ---- R(i+1)
+                const int f = i + 1;
 #pragma unroll
-            for (int ff = 0; ff < kFPB; ++ff) {
-                const int f = f0 + ff;
-                if (f < G::kMF) {
-                    float v[NFRAG * 4];
-#pragma unroll
-                    for (int j = 0; j < NFRAG; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaf(acc[f][j][r], A.accScale, bv[j * 4 + r]);
-                    unsigned char* lrowp = ebuf + ff * kFragBytes + li * kRowS;
-                    if (hasRes) {
-                        u32x4 rp[kNP];
-#pragma unroll
-                        for (int k = 0; k < kNP; ++k) rp[k] = *reinterpret_cast<const u32x4*>(lrowp + pieceOff(k));
-                        if constexpr (PREC == kFp32) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[k * 4 + i] += __uint_as_float(rp[k][i]);
-                        } else if constexpr (kSplit) {
-#pragma unroll
-                            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    v[k * 8 + 2 * i] += f16BitsToF32((uint16_t)(rp[k][i] & 0xffffu)) +
-                                                        f16BitsToF32((uint16_t)(rp[2 + k][i] & 0xffffu));
-                                    v[k * 8 + 2 * i + 1] += f16BitsToF32((uint16_t)(rp[k][i] >> 16)) +
-                                                            f16BitsToF32((uint16_t)(rp[2 + k][i] >> 16));
-                                }
-                        } else if constexpr (kM8) {
-                            constexpr float kLoInv = 1.0f / (float)(1 << kM8LoShift);
-                            typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) { // dword d of the lo piece = channels 4d .. 4d+3
-                                const f32x2 l01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)rp[3][d], false);
-                                const f32x2 l23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)rp[3][d], true);
-                                const uint32_t h01 = rp[d >> 1][(d & 1) * 2], h23 = rp[d >> 1][(d & 1) * 2 + 1];
-                                v[4 * d + 0] += f16BitsToF32((uint16_t)(h01 & 0xffffu)) + l01[0] * kLoInv;
-                                v[4 * d + 1] += f16BitsToF32((uint16_t)(h01 >> 16)) + l01[1] * kLoInv;
-                                v[4 * d + 2] += f16BitsToF32((uint16_t)(h23 & 0xffffu)) + l23[0] * kLoInv;
-                                v[4 * d + 3] += f16BitsToF32((uint16_t)(h23 >> 16)) + l23[1] * kLoInv;
-                            }
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    v[k * 8 + 2 * i] += unpackLo<PREC>(rp[k][i]);
-                                    v[k * 8 + 2 * i + 1] += unpackHi<PREC>(rp[k][i]);
-                                }
-                        }
+                for (int it = 0; it < kIPF; ++it) {
+                    const int r = it * kRPI + lrow;
+                    const int m = f * 16 + r;
+                    u32x4 t = u32x4{0u, 0u, 0u, 0u};
+                    if (f < kPreFrags) {
+                        t = rpre[f < kPreFrags ? f : 0][it];
+                    } else {
+                        if (m < G::kRows)
+                            t = *reinterpret_cast<const u32x4*>(A.res + (row0 + m) * rowBytes + sliceOff + lpc * 16);
                     }
-                    if (A.relu) {
+                    *reinterpret_cast<u32x4*>(ebuf + (f % kRegions) * kFragBytes + r * kRowS + lpc * 16) = t;
+                }
 #pragma unroll
-                        for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
-                    }
-                    u32x4 op[kNP];
+                for (int k = 0; k < kNP; ++k)
+                    rpp[f & 1][k] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + li * kRowS + pieceOff(k));
+            }
+            if (i >= 0 && i < G::kMF) { // ---- X(i)
+                const int f = i;
+                float v[NFRAG * 4];
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaf(acc[f][j][r], A.accScale, bv[j * 4 + r]);
+                unsigned char* lrowp = ebuf + (f % kRegions) * kFragBytes + li * kRowS;
+                if (hasRes) {
+                    const u32x4* rp = rpp[f & 1];
                     if constexpr (PREC == kFp32) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) op[k][i] = __float_as_uint(v[k * 4 + i]);
+                            for (int i = 0; i < 4; ++i) v[k * 4 + i] += __uint_as_float(rp[k][i]);
                     } else if constexpr (kSplit) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                v[k * 8 + 2 * i] += f16BitsToF32((uint16_t)(rp[k][i] & 0xffffu)) +
+                                                    f16BitsToF32((uint16_t)(rp[2 + k][i] & 0xffffu));
+                                v[k * 8 + 2 * i + 1] += f16BitsToF32((uint16_t)(rp[k][i] >> 16)) +
+                                                        f16BitsToF32((uint16_t)(rp[2 + k][i] >> 16));
+                            }
+                    } else if constexpr (kM8) {
+                        constexpr float kLoInv = 1.0f / (float)(1 << kM8LoShift);
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) { // dword d of the lo piece = channels 4d .. 4d+3
+                            const f32x2 l01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)rp[3][d], false);
+                            const f32x2 l23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)rp[3][d], true);
+                            const uint32_t h01 = rp[d >> 1][(d & 1) * 2], h23 = rp[d >> 1][(d & 1) * 2 + 1];
+                            v[4 * d + 0] += f16BitsToF32((uint16_t)(h01 & 0xffffu)) + l01[0] * kLoInv;
+                            v[4 * d + 1] += f16BitsToF32((uint16_t)(h01 >> 16)) + l01[1] * kLoInv;
+                            v[4 * d + 2] += f16BitsToF32((uint16_t)(h23 & 0xffffu)) + l23[0] * kLoInv;
+                            v[4 * d + 3] += f16BitsToF32((uint16_t)(h23 >> 16)) + l23[1] * kLoInv;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                v[k * 8 + 2 * i] += unpackLo<PREC>(rp[k][i]);
+                                v[k * 8 + 2 * i + 1] += unpackHi<PREC>(rp[k][i]);
+                            }
+                    }
+                }
+                if (A.relu) {
+#pragma unroll
+                    for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                u32x4 op[kNP];
+                if constexpr (PREC == kFp32) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) op[k][i] = __float_as_uint(v[k * 4 + i]);
+                } else if constexpr (kSplit) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            uint16_t h0, l0, h1, l1;
+                            splitF16(v[k * 8 + 2 * i], h0, l0);
+                            splitF16(v[k * 8 + 2 * i + 1], h1, l1);
+                            op[k][i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                            op[2 + k][i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                        }
+                } else if constexpr (kM8) {
+                    if (outX3) {
 #pragma unroll
                         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -924,62 +948,44 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                                 op[k][i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
                                 op[2 + k][i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
                             }
-                    } else if constexpr (kM8) {
-                        if (outX3) {
-#pragma unroll
-                            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    uint16_t h0, l0, h1, l1;
-                                    splitF16(v[k * 8 + 2 * i], h0, l0);
-                                    splitF16(v[k * 8 + 2 * i + 1], h1, l1);
-                                    op[k][i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                                    op[2 + k][i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
-                                }
-                        } else {
-                            float hf[16], lf[16];
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) {
-                                const float x = fminf(fmaxf(v[c], -65000.f), 65000.f);
-                                const _Float16 h = (_Float16)x;
-                                const uint32_t hb = __builtin_bit_cast(uint16_t, h);
-                                if (c & 1) op[c >> 3][(c & 7) >> 1] |= hb << 16;
-                                else op[c >> 3][(c & 7) >> 1] = hb;
-                                hf[c] = __builtin_amdgcn_fmed3f((float)h, -448.f, 448.f);
-                                lf[c] = __builtin_amdgcn_fmed3f((x - (float)h) * (float)(1 << kM8LoShift), -448.f, 448.f);
-                            }
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[4 * d], hf[4 * d + 1], 0, false);
-                                h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[4 * d + 2], hf[4 * d + 3], h8, true);
-                                int l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[4 * d], lf[4 * d + 1], 0, false);
-                                l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[4 * d + 2], lf[4 * d + 3], l8, true);
-                                op[2][d] = (uint32_t)h8;
-                                op[3][d] = (uint32_t)l8;
-                            }
-                        }
                     } else {
+                        float hf[16], lf[16];
 #pragma unroll
-                        for (int k = 0; k < 2; ++k)
+                        for (int c = 0; c < 16; ++c) {
+                            const float x = fminf(fmaxf(v[c], -65000.f), 65000.f);
+                            const _Float16 h = (_Float16)x;
+                            const uint32_t hb = __builtin_bit_cast(uint16_t, h);
+                            if (c & 1) op[c >> 3][(c & 7) >> 1] |= hb << 16;
+                            else op[c >> 3][(c & 7) >> 1] = hb;
+                            hf[c] = __builtin_amdgcn_fmed3f((float)h, -448.f, 448.f);
+                            lf[c] = __builtin_amdgcn_fmed3f((x - (float)h) * (float)(1 << kM8LoShift), -448.f, 448.f);
+                        }
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) op[k][i] = packPair<PREC>(v[k * 8 + 2 * i], v[k * 8 + 2 * i + 1]);
+                        for (int d = 0; d < 4; ++d) {
+                            int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[4 * d], hf[4 * d + 1], 0, false);
+                            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[4 * d + 2], hf[4 * d + 3], h8, true);
+                            int l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[4 * d], lf[4 * d + 1], 0, false);
+                            l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[4 * d + 2], lf[4 * d + 3], l8, true);
+                            op[2][d] = (uint32_t)h8;
+                            op[3][d] = (uint32_t)l8;
+                        }
                     }
+                } else {
 #pragma unroll
-                    for (int k = 0; k < kNP; ++k) *reinterpret_cast<u32x4*>(lrowp + pieceOffOut(k)) = op[k];
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) op[k][i] = packPair<PREC>(v[k * 8 + 2 * i], v[k * 8 + 2 * i + 1]);
                 }
+#pragma unroll
+                for (int k = 0; k < kNP; ++k) *reinterpret_cast<u32x4*>(lrowp + pieceOffOut(k)) = op[k];
             }
-            // LDS image -> global, lane-linear: kRPI rows x kRowB contiguous bytes per instruction
+            if (i >= 1) { // ---- S(i-1), stores: kRPI rows x kRowB contiguous bytes per instruction
+                const int f = i - 1;
 #pragma unroll
-            for (int ff = 0; ff < kFPB; ++ff) {
-                if (f0 + ff < G::kMF) {
-#pragma unroll
-                    for (int it = 0; it < kIPF; ++it) {
-                        const int r = it * kRPI + lrow;
-                        const int m = (f0 + ff) * 16 + r;
-                        const u32x4 t = *reinterpret_cast<const u32x4*>(ebuf + ff * kFragBytes + r * kRowS + lpc * 16);
-                        if (m < G::kRows)
-                            *reinterpret_cast<u32x4*>(A.y + (row0 + m) * rowBytes + sliceOff + lpc * 16) = t;
-                    }
+                for (int it = 0; it < kIPF; ++it) {
+                    const int m = f * 16 + it * kRPI + lrow;
+                    if (m < G::kRows)
+                        *reinterpret_cast<u32x4*>(A.y + (row0 + m) * rowBytes + sliceOff + lpc * 16) = tt[it];
                 }
             }
         }
