@@ -87,6 +87,21 @@ def conv_traffic_bytes(args, B):
     return tot / n if n else None
 
 
+def conv_mfma_busy(args, B):
+    """Fraction of the trunk conv's run time its matrix pipes were busy, from the same committed
+    PMC passes: SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES) -- the kernel runs one wave per
+    SIMD and SQ_WAVE_CYCLES counts in units of 4 clocks.  None if not profiled."""
+    if args.net != "20x256" or B != 512:
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01", f"pmc_{args.precision}_summary.json")))
+    except OSError:
+        return None
+    v = [c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_WAVE_CYCLES"]) for name, c in d.items()
+         if "tileKernel" in name and ", 0, 2, 4, 4," in name and c.get("SQ_WAVE_CYCLES")]
+    return sum(v) / len(v) if v else None
+
+
 def quick_rate(nsg, local_rank, blob, bb, B, precision, steps=5):
     """Short device-resident pass of another precision, for context in the same line."""
     import torch
@@ -269,6 +284,7 @@ def main():
                        "weights": "synthetic He-normal seed 0, BN folded, broadcast from rank 0"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": conv_traffic_bytes(args, B),
+                         "mfma_pipe_busy_frac_pmc": conv_mfma_busy(args, B),
                          "mfma_flops_executed_per_algorithmic_flop": MFMA_UNITS[args.precision],
                          "kernel": "tileKernel<kConv> (3x3 conv F->F, bias+residual+ReLU fused)",
                          "avg_launch_ms": conv_ms, "launches_timed": prof["trunk_launches"],
