@@ -396,7 +396,13 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     if (f == 0 && A.stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
                         A.stamps[2048 + kc * 16 + s] = __builtin_amdgcn_s_memtime();
 #endif
-#if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOWRITE)
+#if defined(NSG_EXP_TRASHWRITE)
+                    if (q == kWriteStep) { // timing only: same stores, but every lane to its trash slot
+#pragma unroll
+                        for (int k = 0; k < G::kItems; ++k)
+                            *reinterpret_cast<u32x4*>(smem + G::kLds + lane * 16) = st[k];
+                    }
+#elif !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOWRITE)
                     if (q == kWriteStep) { NSG_STAGE_WRITE((kc + 1) & 1) }
 #endif
 #if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOBAR)
