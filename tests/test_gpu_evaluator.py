@@ -172,6 +172,31 @@ def test_f16m8_extreme_magnitudes_stay_finite(nsg, oracle, monkeypatch):
     assert float(np.abs(out[1] - ref[1]).max()) <= 2e-2
 
 
+def test_f16m8_ragged_batch_sizes_against_f16x3(nsg):
+    """Every board of ragged batches on both sides of the plan boundaries (one- and two-board
+    tiles, one and two chains, the f16x3 fallback) against the f32-equivalent f16x3 evaluator."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    sizes = [3 * cus // 4 - 1, 3 * cus // 4 + 1, cus + 1, 3 * cus // 2 - 1, 2 * cus - 1, 2 * cus + 1, 2 * cus + 88]
+    bmax = max(sizes)
+    w = nsg.weights.make_random(1, 256, seed=50, bn="random")
+    blob = nsg.weights.to_blob(w)
+    a = nsg.Evaluator(0, bmax, 86, precision="f16m8"); a.load_memory(blob)
+    b = nsg.Evaluator(0, bmax, 86, precision="f16x3"); b.load_memory(blob)
+    bb = nsg.synth.random_batch(bmax, 86, seed=51)
+    seen = set()
+    for n in sizes:
+        pa, va, da = a.compute_blocking(bb[:n])
+        plan = a.last_plan()
+        seen.add((plan["trunk_precision"], plan["boards_per_group"], plan["chains"]))
+        pb, vb, db = b.compute_blocking(bb[:n])
+        assert np.isfinite(pa).all()
+        assert float(np.abs(pa - pb).max()) < TOL, (n, plan)
+        assert float(np.abs(va - vb).max()) < TOL and float(np.abs(da - db).max()) < TOL
+    assert ("f16m8", 1, 1) in seen and ("f16m8", 2, 1) in seen and ("f16m8", 2, 2) in seen, seen
+
+
 def test_f16m8_persistent_trunk_kernel_bit_identical(nsg, monkeypatch):
     """NSG_TRUNK_KERNEL=1: all 3x3 layers in one launch (a workgroup owns its boards through
     every layer, no grid barrier).  Same arithmetic, so bit-identical to per-layer launches."""
