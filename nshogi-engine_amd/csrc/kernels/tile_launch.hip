@@ -198,9 +198,14 @@ __global__ __launch_bounds__(256) void valueOutKernel(
     if (b >= batch) return;
     float s0 = 0.f, s1 = 0.f;
     for (int j = lane; j < hidden; j += 64) {
-        // layer 1: the K splits' partial sums in a fixed order, + bias, ReLU
+        // layer 1: the K splits' partial sums in a fixed order, + bias, ReLU (all slices
+        // requested before the first is added: one memory round trip, not nsplit)
+        float part[9];
+#pragma unroll
+        for (int z = 0; z < 9; ++z) part[z] = z < nsplit ? h[(size_t)z * partStride + (size_t)b * hidden + j] : 0.f;
         float hv = b1[j];
-        for (int z = 0; z < nsplit; ++z) hv += h[(size_t)z * partStride + (size_t)b * hidden + j];
+#pragma unroll
+        for (int z = 0; z < 9; ++z) hv += part[z];
         hv = fmaxf(hv, 0.f);
         s0 = fmaf(hv, w2[j], s0);
         s1 = fmaf(hv, w2[hidden + j], s1);
@@ -223,7 +228,7 @@ hipError_t launchValueOut(const float* h, const float* b1, int nsplit, size_t pa
                           const float* w2, const float* b2,
                           float* value, float* draw, int batch, int hidden,
                           hipStream_t stream) {
-    if (batch <= 0 || nsplit < 1) return hipErrorInvalidValue;
+    if (batch <= 0 || nsplit < 1 || nsplit > 9) return hipErrorInvalidValue;
     hipLaunchKernelGGL(valueOutKernel, dim3((batch + 3) / 4), dim3(256), 0, stream,
                        h, b1, nsplit, partStride, w2, b2, value, draw, batch, hidden);
     return hipGetLastError();
