@@ -37,8 +37,8 @@ PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2516.6, "bf16": 2516.6, "f16x3": 2516.6, "
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16", "bf16": "bf16", "f16x3": "f16x3 (split f16 hi/lo, f32 accumulate)",
               "f16m8": "f16m8 (f16 main term + fp8 MX correction terms, f32 accumulate)"}
 # matrix-pipe work per algorithmic MAC in units of one f16 MFMA MAC (the MX instruction
-# retires 4x the K of the f16 one in 2x its cycles; 9 f16 + 5 MX slabs per 9 taps)
-MFMA_UNITS = {"fp32": 1, "fp16": 1, "bf16": 1, "f16x3": 3, "f16m8": (9 + 5 * 2) / 9}
+# retires 4x the K of the f16 one in 2x its cycles; per tap and chunk pair 2 f16 + 1 MX slab)
+MFMA_UNITS = {"fp32": 1, "fp16": 1, "bf16": 1, "f16x3": 3, "f16m8": 2.0}
 
 
 def cpu_baseline(seconds=12.0):

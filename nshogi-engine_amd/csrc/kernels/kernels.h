@@ -44,12 +44,14 @@ inline int slabsPerTap(int prec) { return prec == kF16x3 ? 3 : 2; }
 // Packed weight records per (chunk, tap): the two K halves, or for kF16x3 (w_hi, w_lo)
 // -- w_hi serves both of its products from registers.
 inline int recordsPerTap(int) { return 2; }
-// 1-KiB-per-fragment weight records per channel chunk.  kF16m8: one f16 record per tap
-// (w_hi) plus, per pair of taps, two records holding the 32 fp8 bytes per lane of the MX
-// operand (k-group g: tap 2p + (g>>1), g&1 ? e4m3(w_hi) : e4m3(w_lo)).
+// 1-KiB-per-fragment weight records per channel chunk.  kF16m8 (chunks go in pairs A, B): per
+// tap one f16 record for each chunk (w_hi) plus two records holding the 32 fp8 bytes per lane of
+// the MX operand (k-group g: chunk g>>1, g&1 ? e4m3(w_hi) : e4m3(w_lo)) -- 4 per tap and pair.
 inline int recordsPerChunk(int taps, int prec) {
-    return prec == kF16m8 ? taps + 2 * ((taps + 1) / 2) : taps * recordsPerTap(prec);
+    return prec == kF16m8 ? 2 * taps : taps * recordsPerTap(prec);
 }
+// Input channels are padded to whole chunks; kF16m8 to whole chunk pairs.
+inline int inputChannelGranule(int prec) { return prec == kF16m8 ? 2 * chunkChannels(prec) : chunkChannels(prec); }
 
 // ---- feature-plane expansion (reference K1/K2, src/cuda/extractbit.cu) ----
 hipError_t launchExtractBitsNCHW(float* dst, const uint64_t* src, int batch,

@@ -62,7 +62,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 enum Mode { kConv = 0, kHeads = 1, kDense = 2 };
 
 // SIZE = boards per workgroup (kConv) or 16-row fragments per workgroup.
-template <int MODE, int SIZE, int NWAVES>
+template <int MODE, int SIZE, int NWAVES, int NBUF = 2>
 struct Geom {
     static constexpr bool kBoards = (MODE == kConv);
     static constexpr int kRows = kBoards ? SIZE * 81 : SIZE * 16;
@@ -70,7 +70,7 @@ struct Geom {
     static constexpr int kEntries = kBoards ? SIZE * 110 + 24 : kMF * 16;
     static constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
     static constexpr int kBuf = 8 * kPlane;  // one 128-byte channel chunk
-    static constexpr int kLds = 2 * kBuf;    // double buffered
+    static constexpr int kLds = NBUF * kBuf; // double buffered (kF16m8: four buffers = two chunk pairs)
     // LDS the epilogue may stage through: a two-board tile has the CU to itself (its waves need the
     // whole register file), so it takes the whole 160 KiB and moves 9 of its 11 fragments per batch --
     // the residual loads of a batch are one global round trip, and batches run back to back.
@@ -192,23 +192,21 @@ constexpr int minWavesPerSimd() {
     return (MODE == kConv && SIZE == 1 && (NWAVES >= 3 || NFRAG <= 2) && PREC != kF16m8) ? 2 : 1;
 }
 
-// kF16m8 slab sequence of one channel chunk: m0 m1 X0 m2 m3 X1 ... (m_t: f16 main term of
-// tap t; X_p: fp8 correction terms of taps 2p, 2p+1 on the K=128 MX instruction).
+// kF16m8 slab sequence of one PAIR of channel chunks (A, B): for every tap t the triple
+// A.m_t, B.m_t, X_t -- the f16 main terms of the tap in both chunks, then one K=128 MX slab
+// with the fp8 correction terms of that tap in both chunks (k-group g: chunk g>>1, term g&1).
 template <int TAPS>
 struct M8Seq {
-    static constexpr int kNX = (TAPS + 1) / 2;
-    static constexpr int kSlabs = TAPS + kNX;
-    static constexpr int kFull = 3 * (TAPS / 2);
-    static constexpr bool isX(int s) { return s < kFull ? (s % 3 == 2) : (s == kFull + 1); }
-    static constexpr int tap(int s) { return s < kFull ? 2 * (s / 3) + (s % 3) : TAPS - 1; } // main slabs
-    static constexpr int pair(int s) { return s < kFull ? s / 3 : TAPS / 2; }                // X slabs
-    static constexpr int slabOfTap(int t) { return 3 * (t / 2) + (t & 1); }
-    static constexpr int slabOfPair(int p) { return p < TAPS / 2 ? 3 * p + 2 : kFull + 1; }
-    // record sets (nft x 1 KiB) before slab s: one per main slab, two per X slab
-    static constexpr int recOff(int s) { // closed form: s + (X slabs among the first s)
-        return s + (s <= kFull ? s / 3 : kFull / 3 + (s > kFull + 1 ? 1 : 0));
-    }
-    static constexpr int kRecChunk = TAPS + 2 * kNX;
+    static constexpr int kSlabs = 3 * TAPS;
+    static constexpr bool isX(int s) { return s % 3 == 2; }
+    static constexpr int tap(int s) { return s / 3; }
+    static constexpr int half(int s) { return s % 3; }                 // main slabs: 0 = chunk A, 1 = chunk B
+    static constexpr int mainOrd(int s) { return 2 * (s / 3) + s % 3; } // main slabs in stream order
+    static constexpr int slabOfMain(int o) { return 3 * (o / 2) + (o & 1); }
+    static constexpr int slabOfX(int t) { return 3 * t + 2; }
+    // record sets (nft x 1 KiB) before slab s: per triple one, one, two
+    static constexpr int recOff(int s) { return 4 * (s / 3) + (s % 3 == 2 ? 2 : s % 3); }
+    static constexpr int kRecPair = 4 * TAPS;
 };
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -217,7 +215,7 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 // 2 = decided at run time by A.res (persistent trunk kernel).
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES>
 __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
-    using G = Geom<MODE, SIZE, NWAVES>;
+    using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? 4 : 2)>;
     const bool hasRes = (RES == 1) || (RES == 2 && A.res != nullptr);
     NSG_STAMP(0);
     constexpr bool kM8 = (PREC == kF16m8);
@@ -308,35 +306,32 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         for (int j = 0; j < NFRAG; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if constexpr (kM8) {
-        // ---- kF16m8 main loop: per chunk the slab sequence m0 m1 X0 m2 m3 X1 ... m8 X4 as one
-        // continuous stream of steps (slab, row fragment).  Row fragments live in a rolling
-        // window of kWin register slots and are requested kD steps ahead (a step is 4 MFMAs:
-        // 64 clk for an f16 slab, 128 clk for an MX slab), across slab and chunk boundaries;
-        // the f16 weight records sit in three register sets (requested two main slabs
-        // ahead), the MX records in two (X_p+1 requested at the top of X_p).
+        // ---- kF16m8 main loop over PAIRS of channel chunks: per tap the triple A.m_t, B.m_t, X_t
+        // (M8Seq), 27 slabs per pair, as one continuous stream of steps (slab, row fragment).
+        // Row fragments live in a rolling window of kWin register slots and are requested kD
+        // steps ahead (a step is 4 MFMAs: 64 clk for an f16 slab, 128 clk for an MX slab), across
+        // slab and pair boundaries; the f16 weight records sit in three register sets (requested
+        // two main slabs ahead), the MX records in two (X_t+1 requested at the top of X_t).  An MX
+        // slab needs both chunks' tiles in LDS, so there are four image buffers: the pair being
+        // computed and the pair being staged.
         using Q = M8Seq<G::kTaps>;
-        static_assert(G::kTaps % 3 == 0, "three f16 weight sets must carry across chunks");
+        static_assert((2 * G::kTaps) % 3 == 0, "three f16 weight sets must carry across chunk pairs");
         constexpr int kSteps = Q::kSlabs * G::kMF;
-        constexpr int kWin = 7, kD = 5; // (11 slots / 9 steps of lead: no faster)
-        static_assert(kSteps % kWin == 0, "window slot must carry across chunks");
-        // Next chunk's tile.  All workgroups run in lock-step, so tile loads issued at one
-        // point of the chunk hit HBM/MALL as one 5 MB burst and take > 2 us; and VMEM loads
-        // return in order, so every weight record requested behind them waits that long too.
-        // The tile's items are therefore requested one per slab over slabs 2..7 (X0 m2 m3 X1
-        // m4 m5), each AFTER its step's weight requests, and written to LDS at the top of the
-        // last MX slab, just before the barrier.
-        constexpr int kLoadSlab0 = 2, kLoadSlabs = 6;
-        constexpr int kWriteStep = Q::slabOfPair(Q::kNX - 1) * G::kMF;
-        constexpr int kBarStep = kSteps - kD;       // first step that requests next-chunk fragments
-        static_assert(kWriteStep < kBarStep && (kLoadSlab0 + kLoadSlabs) * G::kMF < kWriteStep, "tile staging order");
+        constexpr int kWin = 9, kD = 7;
+        static_assert(kSteps % kWin == 0, "window slot must carry across chunk pairs");
+        // Next pair's tiles.  All workgroups run in lock-step, so tile loads issued at one point
+        // hit HBM/MALL as one burst and take > 2 us; and VMEM loads return in order, so every
+        // weight record requested behind them waits that long too.  The items are therefore
+        // requested one per slab, each AFTER its step's weight requests: chunk A' over slabs
+        // 2..7, written to LDS at the top of slab 12; chunk B' over slabs 13..18, written at the
+        // top of slab 25; one barrier per pair, just before the first next-pair fragment request.
+        constexpr int kLoadSlabs = 6, kLoadSlabA = 2, kLoadSlabB = 13;
+        constexpr int kWriteStepA = 12 * G::kMF, kWriteStepB = 25 * G::kMF;
+        constexpr int kBarStep = kSteps - kD;
+        static_assert(kWriteStepB < kBarStep, "tile staging order");
         auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
-        // MX operand of lane (li, g): 32 fp8 bytes of tap 2p + (g>>1); g&1 ? lo bytes : hi bytes
-        int offp8[Q::kNX];
-#pragma unroll
-        for (int p = 0; p < Q::kNX; ++p) {
-            const int t0 = 2 * p, t1 = (2 * p + 1 < G::kTaps) ? 2 * p + 1 : 2 * p; // (missing tap: its weights are zero)
-            offp8[p] = (4 + 2 * (g & 1) - g) * G::kPlane + ((g >> 1) ? tapOff(t1) : tapOff(t0));
-        }
+        // MX operand of lane (li, g): 32 fp8 bytes of chunk g>>1 (A / B buffer); g&1 ? lo bytes : hi bytes
+        const int offp8 = (g >> 1) * G::kBuf + (4 + 2 * (g & 1) - g) * G::kPlane;
 #ifdef NSG_EXP_HOTW
         const size_t rs = 0; // diagnostic: every weight record an L1 hit (results are wrong)
 #else
@@ -348,9 +343,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         u32x4 w4[3][NFRAG];
         u32x4 w8[2][NFRAG][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int j = 0; j < NFRAG; ++j) w4[t][j] = wc[Q::recOff(Q::slabOfTap(t)) * rs + wg4 + j * 64];
+            for (int j = 0; j < NFRAG; ++j) w4[o][j] = wc[Q::recOff(Q::slabOfMain(o)) * rs + wg4 + j * 64];
 
         NSG_STAGE_LOAD(0)
         if (zeroLds) {
@@ -360,30 +355,35 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         }
         __syncthreads(); // zero fill done before staging writes
         NSG_STAGE_WRITE(0)
+        NSG_STAGE_LOAD(1)
+        NSG_STAGE_WRITE(1)
         __syncthreads();
         NSG_STAMP(1);
 
         u32x4 aw[kWin][2];
-        // fragment request of step q (q >= kSteps: the next chunk's step q - kSteps)
+        // fragment request of step q (q >= kSteps: the next pair's step q - kSteps)
 #define NSG_M8_REQ(QQ, CUR, NXT)                                                                  \
         {                                                                                         \
             const int q_ = (QQ) % kSteps;                                                         \
             const unsigned char* b_ = ((QQ) >= kSteps) ? (NXT) : (CUR);                           \
             const int s_ = q_ / G::kMF, f_ = q_ % G::kMF;                                         \
             if (Q::isX(s_)) {                                                                     \
-                const unsigned char* ap_ = b_ + abase[f_] + offp8[Q::pair(s_)];                   \
+                const unsigned char* ap_ = b_ + abase[f_] + offp8 + tapOff(Q::tap(s_));           \
                 aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(ap_);                        \
                 aw[(QQ) % kWin][1] = *reinterpret_cast<const u32x4*>(ap_ + G::kPlane);            \
             } else {                                                                              \
-                aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(b_ + abase[f_] + tapOff(Q::tap(s_))); \
+                aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(                             \
+                    b_ + Q::half(s_) * G::kBuf + abase[f_] + tapOff(Q::tap(s_)));                 \
             }                                                                                     \
         }
 #pragma unroll
         for (int q = 0; q < kD; ++q) NSG_M8_REQ(q, smem, smem)
 
-        for (int kc = 0; kc < nkc; ++kc) {
-            const unsigned char* abuf = smem + (kc & 1) * G::kBuf;
-            const unsigned char* nbuf = smem + ((kc + 1) & 1) * G::kBuf;
+        const int npairs = nkc / 2; // (the host pads the input channels to whole pairs)
+        for (int kp = 0; kp < npairs; ++kp) {
+            const unsigned char* abuf = smem + ((2 * kp) & 3) * G::kBuf;
+            const unsigned char* nbuf = smem + ((2 * kp + 2) & 3) * G::kBuf;
+            const int nextA = (kp + 1 < npairs) ? 2 * kp + 2 : 2 * kp; // (last pair: harmless re-load)
             NSG_PIN_ACC_AGPR
 #pragma unroll
             for (int s = 0; s < Q::kSlabs; ++s) {
@@ -394,44 +394,41 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     // slab timeline of workgroup 0 / wave 0, stored behind the per-workgroup stamps
                     // (its s_memtime drains the fragment window: a separate diagnostic build)
                     if (f == 0 && A.stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
-                        A.stamps[2048 + kc * 16 + s] = __builtin_amdgcn_s_memtime();
+                        A.stamps[2048 + kp * 32 + s] = __builtin_amdgcn_s_memtime();
 #endif
-#if defined(NSG_EXP_TRASHWRITE)
-                    if (q == kWriteStep) { // timing only: same stores, but every lane to its trash slot
-#pragma unroll
-                        for (int k = 0; k < G::kItems; ++k)
-                            *reinterpret_cast<u32x4*>(smem + G::kLds + lane * 16) = st[k];
-                    }
-#elif !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOWRITE)
-                    if (q == kWriteStep) { NSG_STAGE_WRITE((kc + 1) & 1) }
+#if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOWRITE)
+                    if (q == kWriteStepA) { NSG_STAGE_WRITE((2 * kp + 2) & 3) }
+                    if (q == kWriteStepB) { NSG_STAGE_WRITE((2 * kp + 3) & 3) }
 #endif
 #if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOBAR)
-                    if (q == kBarStep) __syncthreads(); // publishes the tile written at kWriteStep
+                    if (q == kBarStep) __syncthreads(); // publishes the two tiles written above
 #endif
-                    // MX records: two sets.  X0 is requested at the top of the chunk (set 0 is free once
-                    // the previous chunk's last MX slab is done), X_p+1 at the top of X_p.
-                    const bool reqX = (s == 0) || (Q::isX(s) && Q::pair(s) + 1 < Q::kNX);
+                    // MX records: two sets.  X0 is requested at the top of the pair (set 0 is free once
+                    // the previous pair's last MX slab is done), X_t+1 at the top of X_t.
+                    const bool reqX = (s == 0) || (Q::isX(s) && Q::tap(s) + 1 < G::kTaps);
                     if (f == 0) {
-                        if (!Q::isX(s)) { // f16 record two main slabs ahead (t+2 >= taps: next chunk)
-                            const int t2 = Q::tap(s) + 2;
-                            const size_t o = (t2 >= G::kTaps ? Q::kRecChunk : 0) + Q::recOff(Q::slabOfTap(t2 % G::kTaps));
+                        if (!Q::isX(s)) { // f16 record two main slabs ahead (beyond this pair: the next pair's)
+                            const int o2 = Q::mainOrd(s) + 2;
+                            const size_t o = (o2 >= 2 * G::kTaps ? Q::kRecPair : 0) + Q::recOff(Q::slabOfMain(o2 % (2 * G::kTaps)));
 #pragma unroll
-                            for (int j = 0; j < NFRAG; ++j) w4[t2 % 3][j] = wc[o * rs + wg4 + j * 64];
+                            for (int j = 0; j < NFRAG; ++j) w4[o2 % 3][j] = wc[o * rs + wg4 + j * 64];
                         }
                         if (reqX) {
-                            const int p2 = (s == 0) ? 0 : Q::pair(s) + 1;
-                            const size_t o = Q::recOff(Q::slabOfPair(p2));
+                            const int t2 = (s == 0) ? 0 : Q::tap(s) + 1;
+                            const size_t o = Q::recOff(Q::slabOfX(t2));
 #pragma unroll
                             for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
-                                for (int h = 0; h < 2; ++h) w8[p2 & 1][j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
+                                for (int h = 0; h < 2; ++h) w8[t2 & 1][j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
                         }
                     }
+                    const bool loadA = f == 0 && s >= kLoadSlabA && s < kLoadSlabA + kLoadSlabs;
+                    const bool loadB = f == 0 && s >= kLoadSlabB && s < kLoadSlabB + kLoadSlabs;
 #if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOLOAD)
-                    if (f == 0 && s >= kLoadSlab0 && s < kLoadSlab0 + kLoadSlabs) {
+                    if (loadA || loadB) {
 #pragma unroll
-                        for (int k = s - kLoadSlab0; k < G::kItems; k += kLoadSlabs)
-                            st[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)(kc + 1 < nkc ? kc + 1 : kc) * 128);
+                        for (int k = s - (loadA ? kLoadSlabA : kLoadSlabB); k < G::kItems; k += kLoadSlabs)
+                            st[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)(nextA + (loadB ? 1 : 0)) * 128);
                     }
 #endif
 #ifndef NSG_EXP_NOLDS
@@ -443,8 +440,8 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                                                                  __builtin_bit_cast(i32x4_t, aw[slot][1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                         for (int j = 0; j < NFRAG; ++j) {
-                            const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[Q::pair(s) & 1][j][0]),
-                                                                     __builtin_bit_cast(i32x4_t, w8[Q::pair(s) & 1][j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+                            const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[Q::tap(s) & 1][j][0]),
+                                                                     __builtin_bit_cast(i32x4_t, w8[Q::tap(s) & 1][j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
                             acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 0, 0, 0,
                                                                                         kM8ScaleByte, 0, 127);
                         }
@@ -452,7 +449,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
                         for (int j = 0; j < NFRAG; ++j)
                             acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                __builtin_bit_cast(f16x8, w4[Q::tap(s) % 3][j]), __builtin_bit_cast(f16x8, aw[slot][0]), acc[f][j], 0, 0, 0);
+                                __builtin_bit_cast(f16x8, w4[Q::mainOrd(s) % 3][j]), __builtin_bit_cast(f16x8, aw[slot][0]), acc[f][j], 0, 0, 0);
                     }
                     // issue order inside the step: the first MFMA, then the requests (they issue in its
                     // shadow instead of between two steps), then the other MFMAs
@@ -461,13 +458,12 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     if (f == 0 && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, NFRAG, 0);
                     if (f == 0 && reqX) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NFRAG, 0);
-                    if (f == 0 && s >= kLoadSlab0 && s < kLoadSlab0 + kLoadSlabs)
-                        __builtin_amdgcn_sched_group_barrier(0x020, (G::kItems + kLoadSlabs - 1) / kLoadSlabs, 0);
+                    if (loadA || loadB) __builtin_amdgcn_sched_group_barrier(0x020, (G::kItems + kLoadSlabs - 1) / kLoadSlabs, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NFRAG - 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            wc += (size_t)Q::kRecChunk * rs;
+            wc += (size_t)Q::kRecPair * rs;
         }
 #undef NSG_M8_REQ
         __syncthreads(); // every wave is done reading before the epilogue reuses LDS
@@ -1087,7 +1083,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
 
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES>
 hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
-    using G = Geom<MODE, SIZE, NWAVES>;
+    using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? 4 : 2)>;
     const int gy = a.cout / (NWAVES * NFRAG * 16);
     if (gy < 1 || gy * NWAVES * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
     hipError_t err;
@@ -1119,7 +1115,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
 
 template <int PREC, int SIZE, int NFRAG, int NWAVES>
 hipError_t launchTrunkOne(const Args* layers, int nLayers, int gridX, hipStream_t stream) {
-    using G = Geom<kConv, SIZE, NWAVES>;
+    using G = Geom<kConv, SIZE, NWAVES, (PREC == kF16m8 ? 4 : 2)>;
     auto k = trunkKernel<PREC, SIZE, NFRAG, NWAVES>;
     hipError_t err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
     if (err != hipSuccess) return err;

@@ -62,7 +62,7 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
                          int cout, int relu, float accScale, int prec,
                          const ConvPlan& plan, hipStream_t stream,
                          unsigned long long* stamps, bool outF16x3) {
-    if (batch <= 0 || (cin * elemSize(prec)) % 128 != 0 || cout % 64 != 0)
+    if (batch <= 0 || cin % inputChannelGranule(prec) != 0 || cout % 64 != 0)
         return hipErrorInvalidValue;
     tile::Args a{};
     a.x = (const unsigned char*)x;
@@ -330,41 +330,41 @@ uint8_t hostF32ToE4m3(float v) {
     return sign | (uint8_t)(((ex2 + 7) << 3) | (mant & 7));
 }
 
-// kF16m8 conv weights (see kernels.h): per chunk the slabs m0 m1 X0 m2 m3 X1 ... in stream order.
+// kF16m8 conv weights (see kernels.h): per chunk pair (A, B) and tap t the slabs A.m_t, B.m_t, X_t
+// in stream order.
 void packTileWeightsM8(WeightGetter get, const void* ctx, int taps, int kReal, int kdim, int cout,
                        float scale, unsigned char* out) {
-    const int nkc = kdim / 32;
+    const int npairs = kdim / 64;
     const int nft = cout / 16;
     const size_t recBytes = (size_t)nft * 64 * 16; // one record set: nft fragments x 64 lanes x 16 B
     auto chan = [](int nf, int rho) {
         return (nf / kNfrag) * kNfrag * 16 + (rho >> 2) * 4 * kNfrag + (nf % kNfrag) * 4 + (rho & 3);
     };
-    auto wval = [&](int n, int k, int t) { return (k < kReal && t < taps) ? get(ctx, n, k, t) * scale : 0.f; };
+    auto wval = [&](int n, int k, int t) { return (k < kReal) ? get(ctx, n, k, t) * scale : 0.f; };
     size_t r = 0; // record sets written so far
-    for (int c = 0; c < nkc; ++c) {
+    for (int cp = 0; cp < npairs; ++cp) {
         for (int t = 0; t < taps; ++t) {
-            // main slab: w_hi as 8 f16 per lane
-            for (int nf = 0; nf < nft; ++nf)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int rho = lane & 15, g = lane >> 4, n = chan(nf, rho);
-                    unsigned char* rec = out + r * recBytes + ((size_t)nf * 64 + lane) * 16;
-                    for (int i = 0; i < 8; ++i) {
-                        const _Float16 h = (_Float16)wval(n, c * 32 + 8 * g + i, t);
-                        memcpy(rec + i * 2, &h, 2);
-                    }
-                }
-            ++r;
-            const bool pairEnd = (t & 1) || (t == taps - 1);
-            if (!pairEnd) continue;
-            const int p = t / 2;
-            for (int nf = 0; nf < nft; ++nf)
-                for (int half = 0; half < 2; ++half)
+            for (int half = 0; half < 2; ++half) { // main slabs: w_hi of chunk A, then of chunk B, 8 f16 per lane
+                const int c = 2 * cp + half;
+                for (int nf = 0; nf < nft; ++nf)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int rho = lane & 15, g = lane >> 4, n = chan(nf, rho);
-                        const int tt = 2 * p + (g >> 1);
-                        unsigned char* rec = out + r * recBytes + (((size_t)nf * 2 + half) * 64 + lane) * 16;
+                        unsigned char* rec = out + r * recBytes + ((size_t)nf * 64 + lane) * 16;
+                        for (int i = 0; i < 8; ++i) {
+                            const _Float16 h = (_Float16)wval(n, c * 32 + 8 * g + i, t);
+                            memcpy(rec + i * 2, &h, 2);
+                        }
+                    }
+                ++r;
+            }
+            for (int nf = 0; nf < nft; ++nf) // MX slab: k-group g = (chunk g>>1, term g&1), 32 fp8 per lane
+                for (int h16 = 0; h16 < 2; ++h16)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int rho = lane & 15, g = lane >> 4, n = chan(nf, rho);
+                        const int c = 2 * cp + (g >> 1);
+                        unsigned char* rec = out + r * recBytes + (((size_t)nf * 2 + h16) * 64 + lane) * 16;
                         for (int i = 0; i < 16; ++i) {
-                            const float v = wval(n, c * 32 + 16 * half + i, tt);
+                            const float v = wval(n, c * 32 + 16 * h16 + i, t);
                             const _Float16 h = (_Float16)v;
                             const float lo = v - (float)h;
                             rec[i] = (g & 1) ? hostF32ToE4m3(std::ldexp((float)h, kM8WHiShift))

@@ -525,13 +525,13 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
     if (nv.vh % 64 != 0) return fail(NSG_E_FORMAT, "value hidden width %d is not a multiple of 64", nv.vh);
 
     const int prec = ev->prec;
-    const int kc = nsg::chunkChannels(prec);
+    const int kc = nsg::inputChannelGranule(prec); // input channels are padded to whole chunks (kF16m8: chunk pairs)
     const int es = nsg::elemSize(prec);
     ev->loaded = false;
     ev->F = nv.F; ev->blocks = nv.blocks; ev->vc = nv.vc; ev->vh = nv.vh;
     ev->cpad = roundUp(nv.cin, kc);
     ev->headsCout = roundUp(nv.vc + nv.pc, 64);
-    ev->fc1K = roundUp(81 * nv.vc, kc);
+    ev->fc1K = roundUp(81 * nv.vc, nsg::chunkChannels(nsg::headPrecision(prec)));
     ev->params = nv.params;
 
     std::vector<double> scale;

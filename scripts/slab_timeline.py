@@ -18,13 +18,13 @@ assert lib.nsg_debug_stamps_enable(ev._h) == 0
 for _ in range(2): ev.forward_resident(B)
 buf = np.zeros((2 * blocks, 4096 * 8), dtype=np.uint64)
 assert lib.nsg_debug_stamps_read(ev._h, buf.ctypes.data) == 0
-names = "m0 m1 X0 m2 m3 X1 m4 m5 X2 m6 m7 X3 m8 X4".split()
-t = buf[2:, 2048:2048 + 8 * 16].astype(np.float64).reshape(-1, 8, 16)[:, :, :14]   # layer, chunk, slab
-d = np.diff(t.reshape(t.shape[0], 8 * 14), axis=1)                                 # consecutive slab starts
-d = np.concatenate([d, np.full((d.shape[0], 1), np.nan)], axis=1).reshape(-1, 8, 14)
+names = [n for t in range(9) for n in (f"A.m{t}", f"B.m{t}", f"X{t}")]
+t = buf[2:, 2048:2048 + 4 * 32].astype(np.float64).reshape(-1, 4, 32)[:, :, :27]   # layer, chunk pair, slab
+d = np.diff(t.reshape(t.shape[0], 4 * 27), axis=1)                                 # consecutive slab starts
+d = np.concatenate([d, np.full((d.shape[0], 1), np.nan)], axis=1).reshape(-1, 4, 27)
 print("ideal: m 704, X 1408 cycles")
 print("slab  " + " ".join(f"{n:>6s}" for n in names))
-for kc in range(8):
-    print(f"kc={kc}  " + " ".join(f"{np.nanmean(d[:, kc, s]):6.0f}" for s in range(14)))
-m = np.nanmean(d[:, 1:7, :], axis=(0, 1))
-print("mean  " + " ".join(f"{x:6.0f}" for x in m), " chunk total", round(float(m.sum())))
+for kp in range(4):
+    print(f"pair={kp}  " + " ".join(f"{np.nanmean(d[:, kp, s]):6.0f}" for s in range(27)))
+m = np.nanmean(d[:, 1:3, :], axis=(0, 1))
+print("mean  " + " ".join(f"{x:6.0f}" for x in m), " pair total", round(float(m.sum())))
