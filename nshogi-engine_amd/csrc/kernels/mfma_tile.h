@@ -347,7 +347,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
             for (int j = 0; j < NFRAG; ++j) w4[o][j] = wc[Q::recOff(Q::slabOfMain(o)) * rs + wg4 + j * 64];
 
+        // first pair's tiles: both requested up front (the loop's operand registers are not live yet)
+        u32x4 st1[G::kItems];
         NSG_STAGE_LOAD(0)
+#pragma unroll
+        for (int k = 0; k < G::kItems; ++k) st1[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + 128);
         if (zeroLds) {
             for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
                 reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -355,8 +359,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         }
         __syncthreads(); // zero fill done before staging writes
         NSG_STAGE_WRITE(0)
-        NSG_STAGE_LOAD(1)
-        NSG_STAGE_WRITE(1)
+#pragma unroll
+        for (int k = 0; k < G::kItems; ++k)
+            *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? G::kBuf : 0) + dstOff[k]) = st1[k];
         __syncthreads();
         NSG_STAMP(1);
 
