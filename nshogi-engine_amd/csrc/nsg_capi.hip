@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -20,6 +21,7 @@
 #include <memory>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -251,10 +253,11 @@ int drainProfile(nsg_evaluator* ev) {
     return NSG_OK;
 }
 
-int uploadLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int kdim,
-                int cout, int coutReal, int prec, const std::vector<float>& bias, ConvLayer* L) {
-    const size_t bytes = nsg::tileWeightRecords(taps, kdim, cout, prec) * 16;
-    std::vector<unsigned char> host(bytes);
+// Host half of a layer upload: picks the power-of-two weight scale and packs the fragment
+// records.  Pure function of its arguments (runs on worker threads at load time).
+void packLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int kdim, int cout,
+               int coutReal, int prec, std::vector<unsigned char>* host, float* accScale) {
+    host->assign(nsg::tileWeightRecords(taps, kdim, cout, prec) * 16, 0);
     float scale = 1.f;
     if (prec == nsg::kF16x3 || prec == nsg::kF16m8) {
         // power-of-two scale putting the largest |w| in [2^8, 2^9): hi and lo of every
@@ -269,11 +272,17 @@ int uploadLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int
             scale = std::ldexp(1.0f, 9 - e);
         }
     }
-    L->accScale = 1.0f / scale;
-    nsg::packTileWeights(get, ctx, taps, kReal, kdim, cout, prec, scale, host.data());
-    int rc = L->w.alloc(bytes, false);
+    *accScale = 1.0f / scale;
+    nsg::packTileWeights(get, ctx, taps, kReal, kdim, cout, prec, scale, host->data());
+}
+
+// Device half: allocation and copies (caller's thread, bound to the evaluator's device).
+int commitLayer(const std::vector<unsigned char>& host, float accScale, int kdim, int cout,
+                const std::vector<float>& bias, ConvLayer* L) {
+    L->accScale = accScale;
+    int rc = L->w.alloc(host.size(), false);
     if (rc) return rc;
-    NSG_HIP(hipMemcpy(L->w.p, host.data(), bytes, hipMemcpyHostToDevice));
+    NSG_HIP(hipMemcpy(L->w.p, host.data(), host.size(), hipMemcpyHostToDevice));
     std::vector<float> b(cout, 0.f);
     for (size_t i = 0; i < bias.size() && i < (size_t)cout; ++i) b[i] = bias[i];
     rc = L->bias.alloc((size_t)cout * 4, false);
@@ -281,6 +290,14 @@ int uploadLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int
     NSG_HIP(hipMemcpy(L->bias.p, b.data(), (size_t)cout * 4, hipMemcpyHostToDevice));
     L->cin = kdim;
     return NSG_OK;
+}
+
+int uploadLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int kdim,
+                int cout, int coutReal, int prec, const std::vector<float>& bias, ConvLayer* L) {
+    std::vector<unsigned char> host;
+    float accScale = 1.f;
+    packLayer(get, ctx, taps, kReal, kdim, cout, coutReal, prec, &host, &accScale);
+    return commitLayer(host, accScale, kdim, cout, bias, L);
 }
 
 int roundUp(int a, int b) { return (a + b - 1) / b * b; }
@@ -536,29 +553,54 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
 
     std::vector<double> scale;
     std::vector<float> bias;
-    // stem
-    foldBn(nv.stemBn, nv.F, nv.eps, &scale, &bias);
-    {
-        Conv3Ctx c{nv.stemW, scale.data(), nv.cin};
-        if ((rc = uploadLayer(conv3Get, &c, 9, nv.cin, ev->cpad, nv.F, nv.F, prec, bias, &ev->stem))) return rc;
-        if (prec == nsg::kF16m8 &&
-            (rc = uploadLayer(conv3Get, &c, 9, nv.cin, ev->cpad, nv.F, nv.F, nsg::kF16x3, bias, &ev->stemX3))) return rc;
-    }
-    ev->conv1.clear(); ev->conv2.clear();
-    ev->conv1.resize(nv.blocks); ev->conv2.resize(nv.blocks);
-    ev->conv1X3.clear(); ev->conv2X3.clear();
-    if (prec == nsg::kF16m8) { ev->conv1X3.resize(nv.blocks); ev->conv2X3.resize(nv.blocks); }
-    for (int k = 0; k < nv.blocks; ++k) {
-        foldBn(nv.bn1[k], nv.F, nv.eps, &scale, &bias);
-        Conv3Ctx c1{nv.w1[k], scale.data(), nv.F};
-        if ((rc = uploadLayer(conv3Get, &c1, 9, nv.F, nv.F, nv.F, nv.F, prec, bias, &ev->conv1[k]))) return rc;
-        if (prec == nsg::kF16m8 &&
-            (rc = uploadLayer(conv3Get, &c1, 9, nv.F, nv.F, nv.F, nv.F, nsg::kF16x3, bias, &ev->conv1X3[k]))) return rc;
-        foldBn(nv.bn2[k], nv.F, nv.eps, &scale, &bias);
-        Conv3Ctx c2{nv.w2[k], scale.data(), nv.F};
-        if ((rc = uploadLayer(conv3Get, &c2, 9, nv.F, nv.F, nv.F, nv.F, prec, bias, &ev->conv2[k]))) return rc;
-        if (prec == nsg::kF16m8 &&
-            (rc = uploadLayer(conv3Get, &c2, 9, nv.F, nv.F, nv.F, nv.F, nsg::kF16x3, bias, &ev->conv2X3[k]))) return rc;
+    {   // 3x3 layers: BN folding and fragment packing on worker threads, uploads on this one
+        struct Job {
+            std::vector<double> scale;
+            std::vector<float> bias;
+            const float* w;
+            int cinReal, kdim, prec;
+            ConvLayer* L;
+            std::vector<unsigned char> host;
+            float accScale = 1.f;
+        };
+        ev->conv1.clear(); ev->conv2.clear();
+        ev->conv1.resize(nv.blocks); ev->conv2.resize(nv.blocks);
+        ev->conv1X3.clear(); ev->conv2X3.clear();
+        if (prec == nsg::kF16m8) { ev->conv1X3.resize(nv.blocks); ev->conv2X3.resize(nv.blocks); }
+        std::vector<Job> jobs;
+        auto add = [&](const float* w, const float* bn, int cinReal, int kdim, ConvLayer* L, ConvLayer* Lx3) {
+            Job j;
+            foldBn(bn, nv.F, nv.eps, &j.scale, &j.bias);
+            j.w = w; j.cinReal = cinReal; j.kdim = kdim; j.prec = prec; j.L = L;
+            jobs.push_back(j);
+            if (prec == nsg::kF16m8) { // the f16x3 copy of the trunk (small batches)
+                j.prec = nsg::kF16x3; j.L = Lx3;
+                jobs.push_back(std::move(j));
+            }
+        };
+        add(nv.stemW, nv.stemBn, nv.cin, ev->cpad, &ev->stem, &ev->stemX3);
+        for (int k = 0; k < nv.blocks; ++k) {
+            add(nv.w1[k], nv.bn1[k], nv.F, nv.F, &ev->conv1[k], prec == nsg::kF16m8 ? &ev->conv1X3[k] : nullptr);
+            add(nv.w2[k], nv.bn2[k], nv.F, nv.F, &ev->conv2[k], prec == nsg::kF16m8 ? &ev->conv2X3[k] : nullptr);
+        }
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < jobs.size();) {
+                Job& j = jobs[i];
+                Conv3Ctx c{j.w, j.scale.data(), j.cinReal};
+                packLayer(conv3Get, &c, 9, j.cinReal, j.kdim, nv.F, nv.F, j.prec, &j.host, &j.accScale);
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nthreads = std::min<size_t>(jobs.size(), std::max(1u, std::min(hw ? hw : 1u, 8u)));
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+        for (Job& j : jobs) {
+            if ((rc = commitLayer(j.host, j.accScale, j.kdim, nv.F, j.bias, j.L))) return rc;
+            std::vector<unsigned char>().swap(j.host);
+        }
     }
     // heads: [value conv (BN folded) | policy conv | zero pad]
     {
