@@ -372,7 +372,11 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     const int B = (int)n;
     hipStream_t s = ev->stream;
     // the tile plan is chosen for the whole batch: all chains run concurrently
-    const nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount, ev->tuning);
+    nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount, ev->tuning);
+    // kF16m8 keeps four image buffers in LDS (125 KB for two boards): a CU holds one two-board
+    // workgroup, so where the channel count only allows two-wave workgroups (F = 384) one-board
+    // tiles (74 KB) keep all four SIMDs busy with two workgroups per CU
+    if (ev->prec == nsg::kF16m8 && plan.nfrag == 4 && plan.nwaves <= 2 && ev->tuning.nb == 0) plan.nb = 1;
 
     const bool prof = ev->profile;
     if (prof && ev->evUsed + 4 > (int)ev->ev.size()) {
