@@ -1,6 +1,6 @@
 // mfma_tile.h -- the MFMA tile kernel behind every contraction of the
-// policy/value/draw network on gfx950 (CDNA4).  Included by the three
-// per-precision translation units mfma_tile_{fp32,fp16,bf16}.hip.
+// policy/value/draw network on gfx950 (CDNA4).  Included by the per-precision
+// translation units mfma_tile_{fp32,fp16,bf16,f16x3,f16m8}.hip.
 //
 // It is the body of the opaque TensorRT engine the reference enqueues at
 // src/infer/trt.cc:261 (F1 in SURVEY.md 2b; a7 in 8a).  Nothing here is
@@ -38,9 +38,15 @@
 //   the residual and writes the result with wide row-contiguous vector
 //   accesses and no LDS transpose.
 //
+// * The epilogue stages each fragment through LDS so that every global access of
+//   the residual read and the output write is a full-line, lane-linear 16-byte
+//   access, software-pipelined over the fragments.
+//
 // Precisions: f32 operands -> v_mfma_f32_16x16x4_f32 (exact f32 FMA chain);
-// f16/bf16 operands -> v_mfma_f32_16x16x32_{f16,bf16}; accumulation is f32
-// in all cases.
+// f16/bf16 operands -> v_mfma_f32_16x16x32_{f16,bf16}; kF16x3: split f16 hi/lo,
+// three f16 products per MAC; kF16m8: f16 main term + the two correction terms
+// on fp8 copies by v_mfma_scale_f32_16x16x128_f8f6f4, over pairs of channel
+// chunks (its own main loop below).  Accumulation is f32 in all cases.
 #ifndef NSG_MFMA_TILE_H
 #define NSG_MFMA_TILE_H
 
