@@ -11,7 +11,7 @@
 //   mutex feed queue (feedqueue.h:26-80).
 //
 // usage: pipeline_bench <weights.nsgw> <mode> [seconds=5] [producers=4] [batch=512]
-//                       [depth=2] [feeders=4] [precision=3]
+//                       [depth=2] [feeders=4] [precision=4]
 #include <nshogi_engine_amd/evaluate/batchpipeline.h>
 #include <nshogi_engine_amd/evaluate/evaluator.h>
 #include <nshogi_engine_amd/infer/hip.h>
@@ -84,7 +84,7 @@ int main(int Argc, char* Argv[]) {
     const std::size_t Batch = Argc > 5 ? std::stoul(Argv[5]) : 512;
     const std::size_t Depth = Argc > 6 ? std::stoul(Argv[6]) : 2;
     const std::size_t Feeders = Argc > 7 ? std::stoul(Argv[7]) : 4;
-    const int Precision = Argc > 8 ? std::stoi(Argv[8]) : NSG_PRECISION_F16X3;
+    const int Precision = Argc > 8 ? std::stoi(Argv[8]) : NSG_PRECISION_F16M8;
 
     const Base B;
     std::atomic<bool> Stop{false};
