@@ -69,13 +69,14 @@ struct ConvPlan {
     int nb;      // boards per workgroup
     int nfrag;   // 16-channel output fragments per wave (fixed at pack time)
     int nwaves;  // waves per workgroup
+    int msplit = 1; // wave groups that split the tile's row fragments between them (small one-board tiles: 2)
 };
 constexpr int kNfrag = 4; // every packed tensor uses 4 fragments (64 channels) per wave
 
 // Tuning overrides (0 = automatic), read from NSG_CONV_NB / _NWAVES / _NFRAG when an
 // evaluator is created.
 struct ConvTuning {
-    int nb = 0, nwaves = 0, nfrag = 0;
+    int nb = 0, nwaves = 0, nfrag = 0, msplit = 0; // msplit: NSG_CONV_MSPLIT (1 = never split rows)
     bool fullTilesOnly = false; // kF16m8: 4 fragments per wave at every batch size
 };
 ConvTuning readConvTuning();

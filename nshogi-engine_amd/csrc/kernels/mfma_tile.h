@@ -219,7 +219,11 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 // One layer's work for this workgroup.  RES: 0 = no residual, 1 = residual,
 // 2 = decided at run time by A.res (persistent trunk kernel).
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES>
+// MS (row split, small one-board tiles): the waves of a workgroup form MS groups, each computing
+// 1/MS of the tile's row fragments for NWAVES/MS channel slices, instead of every wave reading every
+// row fragment -- a one-fragment-per-wave tile is LDS-bandwidth-bound, and two fragments per wave on
+// half the rows is the same work per wave for half the LDS reads.
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1>
 __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
     using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? 4 : 2)>;
     const bool hasRes = (RES == 1) || (RES == 2 && A.res != nullptr);
@@ -229,6 +233,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     constexpr bool kSplit = (PREC == kF16x3);
     static_assert(!kM8 || (MODE == kConv && NFRAG == 4), "kF16m8: full trunk-conv tiles only");
     static_assert(NFRAG == 1 || NFRAG == 2 || NFRAG == 4, "fragments per wave");
+    static_assert(MS == 1 || (MODE == kConv && NFRAG < 4 && G::kMF % MS == 0 && NWAVES % MS == 0 && PREC != kF16m8),
+                  "row split: small conv tiles only");
+    constexpr int kMFw = G::kMF / MS; // row fragments this wave computes
 
     int tidOpaque = threadIdx.x;
     // (opaque to the optimiser: inside the persistent trunk kernel the per-lane address tables
@@ -248,15 +255,16 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         nkc = per;
     }
     const int nft = A.cout / 16;
-    const int waveGroup = blockIdx.y * NWAVES + wave; // group of NFRAG fragments
+    const int waveGroup = (blockIdx.y * NWAVES + wave) / MS; // group of NFRAG channel fragments
+    const int fBase = (MS > 1) ? (wave % MS) * kMFw : 0;     // first row fragment of this wave
     // kConv buffers are sized for whole workgroups; flat modes clamp rows.
     const size_t lastRow = G::kBoards ? ~(size_t)0 : (size_t)(A.totalRows - 1);
 
     // per-lane LDS read bases of the row fragments
-    int abase[G::kMF];
+    int abase[kMFw];
 #pragma unroll
-    for (int f = 0; f < G::kMF; ++f) {
-        const int m = f * 16 + li;
+    for (int f = 0; f < kMFw; ++f) {
+        const int m = (fBase + f) * 16 + li;
         if constexpr (G::kBoards) {
             const int p = (m < G::kRows) ? entryOfRow<true>(m) : 11; // 11: every tap reads zeros
             abase[f] = g * G::kPlane + (p - 11) * 16;
@@ -291,7 +299,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     // top and the bottom of the unrolled body and rotates all 176 of them through
     // v_accvgpr_read/mov (~360 instructions per chunk, each waiting on the matrix pipe).
 #define NSG_PIN_ACC_AGPR                                                                 \
-    _Pragma("unroll") for (int f = 0; f < G::kMF; ++f) {                                 \
+    _Pragma("unroll") for (int f = 0; f < kMFw; ++f) {                                   \
         _Pragma("unroll") for (int j = 0; j < NFRAG; ++j) asm volatile("" : "+a"(acc[f][j])); \
     }
     // (macros, not lambdas: a by-reference capture keeps st[] in scratch)
@@ -305,9 +313,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             st[k];                                                                       \
     }
 
-    f32x4 acc[G::kMF][NFRAG];
+    f32x4 acc[kMFw][NFRAG];
 #pragma unroll
-    for (int f = 0; f < G::kMF; ++f)
+    for (int f = 0; f < kMFw; ++f)
 #pragma unroll
         for (int j = 0; j < NFRAG; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -534,7 +542,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     __syncthreads();
 
     NSG_STAMP(1);
-    u32x4 a[kRingA][G::kMF]; // row fragments: current slab + the next kRingA-1
+    u32x4 a[kRingA][kMFw]; // row fragments: current slab + the next kRingA-1
     // Long chunks (3x3 taps) run one continuous slab pipeline across chunk boundaries:
     // the next chunk's tile is written to the other LDS buffer a third of the way into
     // the chunk, the barrier that publishes it sits kRingA slabs before the end, and the
@@ -565,7 +573,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
         for (int q = 0; q < (kSlot ? kSlotR - 1 : kRingA - 1); ++q)
 #pragma unroll
-            for (int f = 0; f < G::kMF; ++f)
+            for (int f = 0; f < kMFw; ++f)
                 a[q][f] = *reinterpret_cast<const u32x4*>(smem + abase[f] + slabOff(kSlot ? 2 * q : q));
     }
     for (int kc = 0; kc < nkc; ++kc) {
@@ -575,7 +583,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
             for (int q = 0; q < kRingA - 1; ++q) // first slabs of this chunk (just published by the barrier)
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f)
+                for (int f = 0; f < kMFw; ++f)
                     if (q < kSlabs) a[q][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + slabOff(q));
         }
         // next chunk's tile: global -> registers, registers -> LDS later
@@ -599,20 +607,20 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     const unsigned char* src = (nt < G::kTaps) ? abuf : nbuf;
                     const int off1 = slabOff(3 * (nt % G::kTaps) + (nlo ? 2 : 0));
 #pragma unroll
-                    for (int f = 0; f < G::kMF; ++f)
+                    for (int f = 0; f < kMFw; ++f)
                         a[(2 * nt + (nlo ? 1 : 0)) % kSlotR][f] =
                             *reinterpret_cast<const u32x4*>(src + abase[f] + off1);
                 }
             } else if (s + kRingA - 1 < kSlabs) {
                 const int off1 = slabOff(s + kRingA - 1);
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f)
+                for (int f = 0; f < kMFw; ++f)
                     a[(s + kRingA - 1) % kRingA][f] = *reinterpret_cast<const u32x4*>(abuf + abase[f] + off1);
             } else if constexpr (kFlow) {
                 // first slabs of the next chunk (after the last chunk: a harmless re-read)
                 const int off1 = slabOff(s + kRingA - 1 - kSlabs);
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f)
+                for (int f = 0; f < kMFw; ++f)
                     a[(s + kRingA - 1) % kRingA][f] = *reinterpret_cast<const u32x4*>(nbuf + abase[f] + off1);
             }
             // -- weight records for later slabs, and which set this slab multiplies by
@@ -654,7 +662,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
             for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f) mfmaSlab<PREC>(acc[f][j], w[wset][j], a[aslot][f]);
+                for (int f = 0; f < kMFw; ++f) mfmaSlab<PREC>(acc[f][j], w[wset][j], a[aslot][f]);
             if constexpr (kWMode == 0) {
                 if constexpr (kRing == 2) {
 #pragma unroll
@@ -665,7 +673,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             if constexpr (kRing >= 3) {
                 // interleave: one LDS read (+ one weight load) per NFRAG row-fragment MFMAs
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f) {
+                for (int f = 0; f < kMFw; ++f) {
                     if (dsReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
                     if (wLoads && f < NFRAG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
                     if (kFlow && s < kLoadSlabs && f == NFRAG) __builtin_amdgcn_sched_group_barrier(0x020, kItemsPerSlab, 0); // tile items
@@ -708,8 +716,8 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // ---- small-batch tiles (1 or 2 fragments per wave): direct stores from the
         // MFMA layout; these launches are latency-bound, not bandwidth-bound.
 #pragma unroll
-        for (int f = 0; f < G::kMF; ++f) {
-            const int m = f * 16 + li;
+        for (int f = 0; f < kMFw; ++f) {
+            const int m = (fBase + f) * 16 + li;
             if (m >= G::kRows) continue;
             const size_t grow = row0 + m;
             float v[NFRAG * 4];
@@ -1058,10 +1066,10 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     }
 }
 
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES>
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES, int MS = 1>
 __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG, PREC>())) void tileKernel(const Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0>(A, smem, true);
+    tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS>(A, smem, true);
 }
 
 // Persistent trunk: one launch runs every 3x3 layer (stem + 2 per residual block)
@@ -1092,14 +1100,14 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
     }
 }
 
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES>
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int MS = 1>
 hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
     using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? 4 : 2)>;
-    const int gy = a.cout / (NWAVES * NFRAG * 16);
-    if (gy < 1 || gy * NWAVES * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
+    const int gy = a.cout / (NWAVES / MS * NFRAG * 16);
+    if (gy < 1 || gy * (NWAVES / MS) * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
     hipError_t err;
     if (MODE == kConv && a.res) {
-        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, (MODE == kConv)>;
+        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, (MODE == kConv), MS>;
         static std::atomic<int> attrDevMask{0}; // per kernel instantiation: devices whose attribute is set
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1110,7 +1118,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
         }
         hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a);
     } else {
-        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false>;
+        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false, MS>;
         static std::atomic<int> attrDevMask{0};
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1153,6 +1161,7 @@ hipError_t launchConvPrec(const Args& a, int batch, const ConvPlan& p, hipStream
     NSG_CASE(2, 4, 4) NSG_CASE(2, 4, 3) NSG_CASE(2, 4, 2) NSG_CASE(2, 4, 1)
     NSG_CASE(1, 4, 4) NSG_CASE(1, 4, 3) NSG_CASE(1, 4, 2) NSG_CASE(1, 4, 1)
     // small-batch tiles: fewer channels per wave, four waves share one input image
+    if (p.msplit == 2 && p.nb == 1 && p.nfrag == 2 && p.nwaves == 4) return launchOne<PREC, kConv, 1, 2, 4, 2>(a, gx, stream);
     NSG_CASE(2, 2, 4) NSG_CASE(2, 1, 4) NSG_CASE(1, 2, 4) NSG_CASE(1, 1, 4)
 #undef NSG_CASE
     return hipErrorInvalidValue;

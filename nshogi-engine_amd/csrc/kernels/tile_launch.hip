@@ -12,6 +12,7 @@ ConvTuning readConvTuning() {
     if (const char* e = getenv("NSG_CONV_NB")) t.nb = atoi(e);
     if (const char* e = getenv("NSG_CONV_NWAVES")) t.nwaves = atoi(e);
     if (const char* e = getenv("NSG_CONV_NFRAG")) t.nfrag = atoi(e);
+    if (const char* e = getenv("NSG_CONV_MSPLIT")) t.msplit = atoi(e);
     return t;
 }
 
@@ -54,6 +55,13 @@ chosen:
         if (v == 4) { p.nfrag = 4; p.nwaves = (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : (groups % 3 == 0) ? 3 : 1; }
     }
     if (kEnvNwaves >= 1 && kEnvNwaves <= 4 && groups % kEnvNwaves == 0 && p.nfrag == kNfrag) p.nwaves = kEnvNwaves;
+    // One board, one fragment per wave: every wave reads every row fragment from LDS for one MFMA
+    // each (LDS-bound).  Two wave groups on half the rows each with two fragments per wave cover
+    // the same 64 channels per workgroup with half the LDS reads.
+    if (p.nb == 1 && p.nfrag == 1 && p.nwaves == 4 && tune.msplit != 1 && kEnvNfrag == 0) {
+        p.nfrag = 2;
+        p.msplit = 2;
+    }
     return p;
 }
 
