@@ -233,8 +233,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     constexpr bool kSplit = (PREC == kF16x3);
     static_assert(!kM8 || (MODE == kConv && NFRAG == 4), "kF16m8: full trunk-conv tiles only");
     static_assert(NFRAG == 1 || NFRAG == 2 || NFRAG == 4, "fragments per wave");
-    static_assert(MS == 1 || (MODE == kConv && NFRAG < 4 && G::kMF % MS == 0 && NWAVES % MS == 0 && PREC != kF16m8),
-                  "row split: small conv tiles only");
+    static_assert(MS == 1 || (MODE == kConv && SIZE == 1 && G::kMF % MS == 0 && NWAVES % MS == 0 &&
+                              (NFRAG < 4 || PREC == kF16m8)),
+                  "row split: one-board conv tiles (small tiles, or kF16m8 full-channel tiles)");
     constexpr int kMFw = G::kMF / MS; // row fragments this wave computes
 
     int tidOpaque = threadIdx.x;
@@ -330,7 +331,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // computed and the pair being staged.
         using Q = M8Seq<G::kTaps>;
         static_assert((2 * G::kTaps) % 3 == 0, "three f16 weight sets must carry across chunk pairs");
-        constexpr int kSteps = Q::kSlabs * G::kMF;
+        constexpr int kSteps = Q::kSlabs * kMFw;
         constexpr int kWin = 9, kD = 7;
         static_assert(kSteps % kWin == 0, "window slot must carry across chunk pairs");
         // Next pair's tiles.  All workgroups run in lock-step, so tile loads issued at one point
@@ -339,9 +340,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // requested one per slab, each AFTER its step's weight requests: chunk A' over slabs
         // 2..7, written to LDS at the top of slab 12; chunk B' over slabs 13..18, written at the
         // top of slab 25; one barrier per pair, just before the first next-pair fragment request.
-        constexpr int kLoadSlabs = 6, kLoadSlabA = 2, kLoadSlabB = 13;
-        constexpr int kWriteStepA = 12 * G::kMF, kWriteStepB = 25 * G::kMF;
+        constexpr int kLoadSlabs = G::kItems < 6 ? G::kItems : 6, kLoadSlabA = 2, kLoadSlabB = 13;
         constexpr int kBarStep = kSteps - kD;
+        constexpr int kWriteStepA = 12 * kMFw, kWriteStepB = 25 * kMFw < kBarStep ? 25 * kMFw : kBarStep - 1;
         static_assert(kWriteStepB < kBarStep, "tile staging order");
         auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
         // MX operand of lane (li, g): 32 fp8 bytes of chunk g>>1 (A / B buffer); g&1 ? lo bytes : hi bytes
@@ -385,7 +386,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         {                                                                                         \
             const int q_ = (QQ) % kSteps;                                                         \
             const unsigned char* b_ = ((QQ) >= kSteps) ? (NXT) : (CUR);                           \
-            const int s_ = q_ / G::kMF, f_ = q_ % G::kMF;                                         \
+            const int s_ = q_ / kMFw, f_ = q_ % kMFw;                                         \
             if (Q::isX(s_)) {                                                                     \
                 const unsigned char* ap_ = b_ + abase[f_] + offp8 + tapOff(Q::tap(s_));           \
                 aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(ap_);                        \
@@ -407,8 +408,8 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
             for (int s = 0; s < Q::kSlabs; ++s) {
 #pragma unroll
-                for (int f = 0; f < G::kMF; ++f) {
-                    const int q = s * G::kMF + f;
+                for (int f = 0; f < kMFw; ++f) {
+                    const int q = s * kMFw + f;
 #ifdef NSG_DIAG_SLABS
                     // slab timeline of workgroup 0 / wave 0, stored behind the per-workgroup stamps
                     // (its s_memtime drains the fragment window: a separate diagnostic build)
@@ -473,7 +474,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     // issue order inside the step: the first MFMA, then the requests (they issue in its
                     // shadow instead of between two steps), then the other MFMAs
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (Q::isX(((q + kD) % kSteps) / G::kMF)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (Q::isX(((q + kD) % kSteps) / kMFw)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     if (f == 0 && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, NFRAG, 0);
                     if (f == 0 && reqX) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NFRAG, 0);
@@ -836,14 +837,14 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // (only the first kPreFrags fragments: with all eleven the epilogue spills; kernels capped at
         // 256 registers for two waves per SIMD request every fragment one pipeline stage ahead instead)
         constexpr int kPreFrags = (RES != 1 || minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG, PREC>() > 1)
-                                      ? 0 : (G::kMF * kIPF <= 32 ? G::kMF : 32 / kIPF);
+                                      ? 0 : (kMFw * kIPF <= 32 ? kMFw : 32 / kIPF);
         u32x4 rpre[kPreFrags ? kPreFrags : 1][kIPF];
         if constexpr (kPreFrags > 0) {
 #pragma unroll
             for (int f = 0; f < kPreFrags; ++f)
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
-                    const int m = f * 16 + it * kRPI + lrow;
+                    const int m = (fBase + f) * 16 + it * kRPI + lrow;
                     rpre[f][it] = u32x4{0u, 0u, 0u, 0u};
                     if (m < G::kRows)
                         rpre[f][it] = *reinterpret_cast<const u32x4*>(A.res + (row0 + m) * rowBytes + sliceOff + lpc * 16);
@@ -862,19 +863,19 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         u32x4 rpp[2][kNP];
         u32x4 tt[kIPF];
 #pragma unroll
-        for (int i = -1; i <= G::kMF; ++i) {
+        for (int i = -1; i <= kMFw; ++i) {
             if (i >= 1) { // ---- S(i-1), reads
                 const int f = i - 1;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it)
                     tt[it] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + (it * kRPI + lrow) * kRowS + lpc * 16);
             }
-            if (hasRes && i + 1 < G::kMF) { // ---- R(i+1)
+            if (hasRes && i + 1 < kMFw) { // ---- R(i+1)
                 const int f = i + 1;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
                     const int r = it * kRPI + lrow;
-                    const int m = f * 16 + r;
+                    const int m = (fBase + f) * 16 + r;
                     u32x4 t = u32x4{0u, 0u, 0u, 0u};
                     if (f < kPreFrags) {
                         t = rpre[f < kPreFrags ? f : 0][it];
@@ -888,7 +889,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 for (int k = 0; k < kNP; ++k)
                     rpp[f & 1][k] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + li * kRowS + pieceOff(k));
             }
-            if (i >= 0 && i < G::kMF) { // ---- X(i)
+            if (i >= 0 && i < kMFw) { // ---- X(i)
                 const int f = i;
                 float v[NFRAG * 4];
 #pragma unroll
@@ -1004,7 +1005,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 const int f = i - 1;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
-                    const int m = f * 16 + it * kRPI + lrow;
+                    const int m = (fBase + f) * 16 + it * kRPI + lrow;
                     if (m < G::kRows)
                         *reinterpret_cast<u32x4*>(A.y + (row0 + m) * rowBytes + sliceOff + lpc * 16) = tt[it];
                 }

@@ -8,6 +8,8 @@ namespace tile {
 hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStream_t s) {
     const int gx = (batch + p.nb - 1) / p.nb;
     if (p.nfrag != 4) return hipErrorInvalidValue;
+    // mid batches: one board per workgroup, two wave groups on three row fragments each
+    if (p.msplit == 2 && p.nb == 1 && p.nwaves == 4) return launchOne<kF16m8, kConv, 1, 4, 4, 2>(a, gx, s);
 #define NSG_CASE(NB_, NW_) \
     if (p.nb == NB_ && p.nwaves == NW_) return launchOne<kF16m8, kConv, NB_, 4, NW_>(a, gx, s);
     NSG_CASE(2, 4) NSG_CASE(2, 3) NSG_CASE(2, 2) NSG_CASE(2, 1)

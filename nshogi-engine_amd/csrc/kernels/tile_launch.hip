@@ -47,6 +47,17 @@ ConvPlan chooseConvPlan(int batch, int cout, int computeUnits, const ConvTuning&
         }
     }
 chosen:
+    // A small-tile plan whose grid needs a second round of workgroups (more workgroups than CUs:
+    // the CUs that get two take twice as long as the rest) loses to one full one-board tile per
+    // board when those tiles fit in one round: B = 129..191 on 256 CUs (129: 2.13 -> 1.9 ms).
+    if (p.nfrag < 4 && tune.nfrag == 0 && tune.nb == 0) {
+        const int perBoard = cout / (16 * p.nfrag * 4); // workgroups per tile of the small plan
+        const int nwg = ((batch + p.nb - 1) / p.nb) * perBoard;
+        if (nwg > computeUnits && batch <= computeUnits && 2 * batch > computeUnits) {
+            p.nb = 1; p.nfrag = 4;
+            p.nwaves = (groups % 4 == 0) ? 4 : (groups % 2 == 0) ? 2 : (groups % 3 == 0) ? 3 : 1;
+        }
+    }
     const int kEnvNb = tune.nb, kEnvNwaves = tune.nwaves, kEnvNfrag = tune.fullTilesOnly ? 4 : tune.nfrag;
     if (kEnvNb == 1 || kEnvNb == 2) p.nb = kEnvNb;
     if (kEnvNfrag) {

@@ -377,6 +377,14 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // workgroup, so where the channel count only allows two-wave workgroups (F = 384) one-board
     // tiles (74 KB) keep all four SIMDs busy with two workgroups per CU
     if (ev->prec == nsg::kF16m8 && plan.nfrag == 4 && plan.nwaves <= 2 && ev->tuning.nb == 0) plan.nb = 1;
+    // Batches too small for full tiles on every CU but with >= 3/4 CU worth of (board, 128-channel)
+    // units -- the engine's default batch of 128 -- run kF16m8 one-board tiles whose four waves are
+    // two row groups x two 64-channel groups, instead of falling back to the kF16x3 small tiles
+    if (ev->prec == nsg::kF16m8 && plan.nfrag != 4 && ev->F % 128 == 0 && ev->tuning.nfrag == 0 &&
+        ev->tuning.msplit != 1 && (long)B * (ev->F / 128) * 4 >= (long)ev->prop.multiProcessorCount * 3 &&
+        (long)B * (ev->F / 128) <= (long)ev->prop.multiProcessorCount) { // (one workgroup per CU: no second round)
+        plan.nb = 1; plan.nfrag = 4; plan.nwaves = 4; plan.msplit = 2;
+    }
 
     const bool prof = ev->profile;
     if (prof && ev->evUsed + 4 > (int)ev->ev.size()) {
