@@ -377,13 +377,16 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // workgroup, so where the channel count only allows two-wave workgroups (F = 384) one-board
     // tiles (74 KB) keep all four SIMDs busy with two workgroups per CU
     if (ev->prec == nsg::kF16m8 && plan.nfrag == 4 && plan.nwaves <= 2 && ev->tuning.nb == 0) plan.nb = 1;
-    // Batches too small for full tiles on every CU but with >= 3/4 CU worth of (board, 128-channel)
-    // units -- the engine's default batch of 128 -- run kF16m8 one-board tiles whose four waves are
-    // two row groups x two 64-channel groups, instead of falling back to the kF16x3 small tiles
+    // Mid batches -- the engine's default batch of 128 and its benchmark's 60..159 -- run kF16m8
+    // one-board tiles whose four waves are two row groups x two 64-channel groups (two workgroups per
+    // board) wherever those fill more than half the CUs in one round of workgroups
     if (ev->prec == nsg::kF16m8 && plan.nfrag != 4 && ev->F % 128 == 0 && ev->tuning.nfrag == 0 &&
-        ev->tuning.msplit != 1 && (long)B * (ev->F / 128) * 4 >= (long)ev->prop.multiProcessorCount * 3 &&
-        (long)B * (ev->F / 128) <= (long)ev->prop.multiProcessorCount) { // (one workgroup per CU: no second round)
-        plan.nb = 1; plan.nfrag = 4; plan.nwaves = 4; plan.msplit = 2;
+        ev->tuning.msplit != 1) {
+        const long cus = ev->prop.multiProcessorCount;
+        const long wgM8 = (long)B * (ev->F / 128);
+        if (wgM8 <= cus && wgM8 * 2 > cus) { // (measured: 1.17-1.29 ms for every B in 65..128; kF16x3 plans 1.26-1.54 ms)
+            plan.nb = 1; plan.nfrag = 4; plan.nwaves = 4; plan.msplit = 2;
+        }
     }
 
     const bool prof = ev->profile;
