@@ -174,11 +174,13 @@ def test_f16m8_extreme_magnitudes_stay_finite(nsg, oracle, monkeypatch):
 
 def test_f16m8_ragged_batch_sizes_against_f16x3(nsg):
     """Every board of ragged batches on both sides of the plan boundaries (one- and two-board
-    tiles, one and two chains, the f16x3 fallback) against the f32-equivalent f16x3 evaluator."""
+    tiles, row-split one-board tiles, one and two chains, the f16x3 fallback) against the
+    f32-equivalent f16x3 evaluator."""
     probe = nsg.Evaluator(0, 1, 86)
     cus = probe.info()["compute_units"]
     del probe
-    sizes = [3 * cus // 4 - 1, 3 * cus // 4 + 1, cus + 1, 3 * cus // 2 - 1, 2 * cus - 1, 2 * cus + 1, 2 * cus + 88]
+    sizes = [cus // 4, cus // 4 + 1, cus // 2 - 1, cus // 2, cus // 2 + 1, 3 * cus // 4 - 1, 3 * cus // 4 + 1, cus, cus + 1,
+             3 * cus // 2 - 1, 2 * cus - 1, 2 * cus + 1, 2 * cus + 88]
     bmax = max(sizes)
     w = nsg.weights.make_random(1, 256, seed=50, bn="random")
     blob = nsg.weights.to_blob(w)
