@@ -329,7 +329,7 @@ def main():
                 bbig = nsg.synth.random_batch(1024, 86, seed=nsg.synth.SEED + 1, distinct=True)
                 big.upload_features(bbig)
                 by_batch = {}
-                for nb in (1, 64, 1024):
+                for nb in (1, 64, 128, 1024):  # 128 = the engine's default BatchSize (context.h:79)
                     big.forward_resident(nb)
                     torch.cuda.synchronize()
                     k = max(4, min(200, int(20 * 512 / nb) // 8))
