@@ -202,7 +202,8 @@ int nsg_get_info(nsg_evaluator* ev, nsg_info* info);
 int nsg_get_last_plan(nsg_evaluator* ev, int* boards_per_group, int* fragments_per_wave,
                       int* waves_per_group, int* chains);
 /* Arithmetic the most recent forward pass ran its trunk in (NSG_PRECISION_*; -1 before
- * the first pass).  An F16M8 evaluator runs batches too small for full tiles as F16X3. */
+ * the first pass).  An F16M8 evaluator runs its smallest batches (up to CUs/4 boards at 256
+ * channels) as F16X3. */
 int nsg_get_last_trunk_precision(nsg_evaluator* ev, int* precision);
 
 /* CPU stand-in executors of the reference (src/infer/zero.cc, nothing.cc,
