@@ -24,7 +24,7 @@ from .capi import (  # noqa: F401
     MOVE_INDEX_MAX,
     NUM_SQUARES,
 )
-from . import weights, synth, dist  # noqa: F401
+from . import weights, synth, dist, onnx_io  # noqa: F401
 
 __all__ = [
     "NsgError", "Evaluator", "CpuExecutor", "extract_bits", "load_library",

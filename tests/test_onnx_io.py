@@ -1,0 +1,74 @@
+"""ONNX bridge (nshogi-engine_amd/onnx_io.py): the writer and the reader are both hand-coded
+protobuf, so these tests pin them against each other and against the oracle; interoperability
+with the real onnx tools is not testable in this image (no onnx / onnxruntime)."""
+import importlib
+import struct
+
+import numpy as np
+import pytest
+
+nsg = importlib.import_module("nshogi-engine_amd")
+oio = nsg.onnx_io
+
+
+def test_varint_and_wire_roundtrip():
+    for v in (0, 1, 127, 128, 300, 2 ** 31, 2 ** 63 - 1):
+        msg = oio._f_varint(3, v) + oio._f_bytes(4, b"abc") + oio._f_float(2, 1.5)
+        fields = list(oio._parse(msg))
+        assert fields[0][:2] == (3, 0) and fields[0][2] == v
+        assert fields[1][0] == 4 and bytes(fields[1][2]) == b"abc"
+        assert struct.unpack("<f", fields[2][2])[0] == 1.5
+    assert oio._signed(list(oio._parse(oio._f_varint(1, -1)))[0][2]) == -1
+
+
+@pytest.mark.parametrize("blocks,channels,bn", [(0, 64, "random"), (2, 64, "random"), (3, 128, "identity")])
+def test_export_import_roundtrip_is_exact(blocks, channels, bn):
+    w = nsg.weights.make_random(blocks, channels, seed=5, bn=bn)
+    data = oio.export_onnx(w)
+    nodes, inits, ins, outs = oio.read_onnx(data)
+    assert ins == ["input"] and outs == ["policy", "value", "draw"]
+    assert sum(n.op == "Conv" for n in nodes) == 1 + 2 * blocks + 2
+    w2 = oio.import_onnx(data)
+    assert w2["_meta"]["blocks"] == blocks and w2["_meta"]["channels"] == channels
+    for k, v in w.items():
+        if k == "_meta":
+            continue
+        np.testing.assert_array_equal(np.asarray(v, np.float32), w2[k], err_msg=k)
+    assert nsg.weights.to_blob(w2) == nsg.weights.to_blob(w)
+
+
+def test_imported_model_evaluates_like_the_original(oracle):
+    w = nsg.weights.make_random(2, 64, seed=9, bn="random")
+    w2 = oio.import_onnx(oio.export_onnx(w))
+    bb = nsg.synth.random_batch(3, 86, seed=4)
+    a = oracle.net(nsg.weights.to_blob(w)).evaluate(bb)
+    b = oracle.net(nsg.weights.to_blob(w2)).evaluate(bb)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_folded_export_with_sigmoid_value_imports_to_an_equivalent_net(oracle):
+    """A model whose convs carry biases instead of BatchNormalization nodes and whose value
+    output is one sigmoid: the importer rebuilds identity BN statistics around the bias and
+    halves the value row; outputs agree with the original to float rounding of the folding."""
+    w = nsg.weights.make_random(2, 64, seed=3, bn="random")
+    data = oio.export_onnx(w, fold_bn=True, value_sigmoid=True)
+    nodes, _, _, _ = oio.read_onnx(data)
+    assert not any(n.op in ("BatchNormalization", "Tanh") for n in nodes)
+    w2 = oio.import_onnx(data)
+    np.testing.assert_array_equal(w2["fc2_w"], np.asarray(w["fc2_w"], np.float32))
+    bb = nsg.synth.random_batch(3, 86, seed=4)
+    a = oracle.net(nsg.weights.to_blob(w)).evaluate(bb)
+    b = oracle.net(nsg.weights.to_blob(w2)).evaluate(bb)
+    for x, y in zip(a, b):
+        assert float(np.abs(x - y).max()) < 2e-5
+
+
+def test_refuses_foreign_structures():
+    w = nsg.weights.make_random(1, 64, seed=1)
+    data = bytearray(oio.export_onnx(w))
+    bad = bytes(data).replace(b"policy", b"polizy")
+    with pytest.raises(ValueError):
+        oio.import_onnx(bad)
+    with pytest.raises(ValueError):
+        oio.import_onnx(b"\x08\x07")
