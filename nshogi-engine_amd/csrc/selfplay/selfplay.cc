@@ -1,5 +1,6 @@
 // selfplay.cc -- see selfplay.h.
 #include "selfplay.h"
+#include "teacher.h"
 
 #include <nshogi_engine_amd/evaluate/evaluator.h>
 
@@ -120,6 +121,8 @@ class Game {
             Config.WhiteDrawValue = 1.0f - Config.BlackDrawValue;
         }
         GameMoves = 0;
+        MoveHistory.clear();
+        FullSearchAt.clear();
         Ph = Phase::RootPreparation;
     }
 
@@ -427,6 +430,8 @@ class Game {
     }
 
     void playMove(Move M) {
+        MoveHistory.push_back(M.V);
+        FullSearchAt.push_back(FullSearch ? 1 : 0); // Frame::DidFullSearch (frame.h), read by saveworker.cc:172-174
         S.doMove(M);
         ++GameMoves;
         ++Eng->St.Moves;
@@ -439,10 +444,11 @@ class Game {
         else if (Winner == shogi::White) ++Eng->St.GamesWhite;
         else ++Eng->St.GamesDraw;
         Eng->St.MovesOfFinishedGames += GameMoves;
+        if (Eng->Teacher) Eng->St.TeacherRecords += Eng->Teacher->saveGame(MoveHistory, FullSearchAt, Config, Winner);
         newGame();
     }
 
-    void judge() { // worker.cc:477-526 (without the df-pn call)
+    void judge() { // worker.cc:477-526
         const shogi::RepetitionStatus RS = S.repetitionStatus(true);
         if (RS == shogi::WinRepetition) return finish(S.sideToMove());
         if (RS == shogi::LossRepetition) return finish(~S.sideToMove());
@@ -452,6 +458,17 @@ class Game {
         S.generateLegalMoves(L);
         if (L.size() == 0) return finish(~S.sideToMove());
         if (S.ply() >= Config.MaxPly) return finish(shogi::NoColor);
+        if (Eng->Opt.DfpnNodes) { // worker.cc:516-524: a proven mate ends the game with the mating move played
+            const Move Mate = Eng->Solver.solve(S, Eng->Opt.DfpnNodes);
+            Eng->St.DfpnNodes += Eng->Solver.nodes();
+            if (!Mate.isNone()) {
+                const Color Winner = S.sideToMove();
+                FullSearch = true; // pushDidFullSearch(true)
+                playMove(Mate);
+                ++Eng->St.DfpnMates;
+                return finish(Winner);
+            }
+        }
         Ph = Phase::RootPreparation;
     }
 
@@ -467,6 +484,8 @@ class Game {
     uint32_t Budget = 1;
     bool FullSearch = false;
     uint32_t GameMoves = 0;
+    std::vector<uint32_t> MoveHistory;  // every move of the current game (for the teacher replay)
+    std::vector<uint8_t> FullSearchAt;  // per ply: was the root search a full search
     Phase Ph = Phase::RootPreparation;
     float Logits[600];
     double Noise[600];

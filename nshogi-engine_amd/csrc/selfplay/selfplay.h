@@ -16,16 +16,18 @@
 //     (the reference seeds from std::random_device, worker.cc:49-50);
 //   * Gumbel mode (worker.cc:428-475 sequential halving, :596-638 transition,
 //     :784-905 sampling / halving schedule) is implemented as in the reference;
-//   * the mate-in-3 search at leaves (worker.cc:349-358) is shogi::State::findMate(3); the
-//     df-pn solver call in judge (worker.cc:516-524, 100 000 nodes) is not implemented:
-//     the game is simply played on;
-//   * the teacher record writer (saveworker.cc:160-182, libnshogi's SimpleTeacher
-//     format) is out of scope; finished games are only counted.
+//   * the mate-in-3 search at leaves (worker.cc:349-358) is shogi::State::findMate(3) and the
+//     df-pn solver call in judge (worker.cc:516-524, 100 000 nodes) is shogi::DfpnSolver
+//     (csrc/shogi/dfpn.h), one solver per engine thread;
+//   * finished games are replayed into teacher records by TeacherWriter (teacher.h; role of
+//     saveworker.cc:160-182) in this build's own record format, libnshogi's SimpleTeacher
+//     byte format being absent with the library.
 // Rules, feature planes and the policy move index come from csrc/shogi (this
 // build's own; parity with libnshogi unpinned).
 #ifndef NSG_SELFPLAY_H
 #define NSG_SELFPLAY_H
 
+#include "../shogi/dfpn.h"
 #include "../shogi/features.h"
 #include "../shogi/shogi.h"
 
@@ -51,6 +53,7 @@ struct Options {
     int MaxPlyMax = 512 + 128;
     bool RandomDrawValue = true; // worker.cc:142-150
     std::size_t EvalCacheEntries = 1 << 15; // per engine; 0 disables
+    uint64_t DfpnNodes = 100000; // node budget of the df-pn mate solver run after every move (worker.cc:516); 0 = off
     bool MateSearch = true;      // mate-in-3 search by checks at every non-root leaf (worker.cc:349-358)
 };
 
@@ -61,8 +64,11 @@ struct Stats {
     uint64_t Playouts = 0;      // back-propagations (incl. terminal and cached leaves)
     uint64_t Moves = 0;
     uint64_t MatesFound = 0;    // leaves closed by the mate-in-3 search
+    uint64_t DfpnMates = 0;     // games ended by the df-pn solver in judge
+    uint64_t DfpnNodes = 0;     // node expansions spent in it
     uint64_t GamesBlack = 0, GamesWhite = 0, GamesDraw = 0;
     uint64_t MovesOfFinishedGames = 0;
+    uint64_t TeacherRecords = 0; // positions written by the teacher writer (full-search plies only)
     uint64_t finished() const { return GamesBlack + GamesWhite + GamesDraw; }
 };
 
@@ -83,6 +89,7 @@ struct Node {
 };
 
 class Game; // one Frame
+class TeacherWriter; // teacher.h
 
 // One engine = one search thread's worth of games + its two executors.
 class Engine {
@@ -97,6 +104,9 @@ class Engine {
     void step();
     void drain(); // await in-flight batches and apply them
 
+    // Finished games are written to W (shared, not owned; nullptr = off).  Set before run().
+    void setTeacherWriter(TeacherWriter* W) { Teacher = W; }
+
     const Stats& stats() const { return St; }
     // order-independent digest of every move played so far (reproducibility checks)
     uint64_t moveDigest() const { return Digest; }
@@ -108,6 +118,8 @@ class Engine {
 
     Options Opt;
     Stats St;
+    TeacherWriter* Teacher = nullptr;
+    shogi::DfpnSolver Solver;
     uint64_t Digest = 0;
     std::unique_ptr<Group> Groups[2];
     struct Cache;

@@ -5,8 +5,10 @@
 //
 // usage: selfplay [--executor hip|random|zero] [--weights file.nsgw] [--gpu 0]
 //                 [--threads 2] [--games-per-group 256] [--playouts 800]
-//                 [--seconds 30] [--max-games 0] [--seed 0] [--precision 3] [--mate-search 1]
+//                 [--seconds 30] [--max-games 0] [--seed 0] [--precision 3] [--mate-search 1] [--dfpn-nodes 100000]
+//                 [--teacher out.nsgt]   (training records of finished games, teacher.h)
 #include "selfplay.h"
+#include "teacher.h"
 
 #include <nshogi_engine_amd/infer/cpu.h>
 #include <nshogi_engine_amd/infer/hip.h>
@@ -22,7 +24,7 @@
 using namespace nshogi::engine;
 
 int main(int Argc, char* Argv[]) {
-    std::string Executor = "hip", Weights;
+    std::string Executor = "hip", Weights, TeacherPath;
     int Gpu = 0, Threads = 2, Precision = NSG_PRECISION_F16X3;
     double Seconds = 30.0;
     uint64_t MaxGames = 0;
@@ -31,6 +33,8 @@ int main(int Argc, char* Argv[]) {
         const std::string K = Argv[I], V = Argv[I + 1];
         if (K == "--executor") Executor = V;
         else if (K == "--weights") Weights = V;
+        else if (K == "--teacher") TeacherPath = V;
+        else if (K == "--dfpn-nodes") Opt.DfpnNodes = std::stoull(V);
         else if (K == "--gpu") Gpu = std::stoi(V);
         else if (K == "--threads") Threads = std::stoi(V);
         else if (K == "--games-per-group") Opt.GamesPerGroup = std::stoi(V);
@@ -64,6 +68,11 @@ int main(int Argc, char* Argv[]) {
     for (int T = 0; T < Threads; ++T)
         Engines.push_back(std::make_unique<selfplay::Engine>(Execs[2 * T].get(), Execs[2 * T + 1].get(), Opt,
                                                              (uint64_t)T, Hip));
+    std::unique_ptr<selfplay::TeacherWriter> Teacher;
+    if (!TeacherPath.empty()) {
+        Teacher = std::make_unique<selfplay::TeacherWriter>(TeacherPath);
+        for (auto& E : Engines) E->setTeacherWriter(Teacher.get());
+    }
     volatile bool Stop = false;
     const auto T0 = std::chrono::steady_clock::now();
     std::vector<std::thread> Workers;
@@ -90,6 +99,7 @@ int main(int Argc, char* Argv[]) {
         S.Playouts += X.Playouts; S.Moves += X.Moves; S.GamesBlack += X.GamesBlack;
         S.GamesWhite += X.GamesWhite; S.GamesDraw += X.GamesDraw;
         S.MovesOfFinishedGames += X.MovesOfFinishedGames; S.MatesFound += X.MatesFound;
+        S.TeacherRecords += X.TeacherRecords; S.DfpnMates += X.DfpnMates; S.DfpnNodes += X.DfpnNodes;
         Digest ^= E->moveDigest() * 0x9e3779b97f4a7c15ULL + (uint64_t)(&E - &Engines[0]);
     }
     const double Fin = (double)S.finished();
@@ -104,6 +114,9 @@ int main(int Argc, char* Argv[]) {
               << ", \"avg_batch\": " << (S.Batches ? (double)S.Evaluations / S.Batches : 0.0)
               << ", \"cache_hit_ratio\": " << (S.Evaluations + S.CacheHits ? (double)S.CacheHits / (S.Evaluations + S.CacheHits) : 0.0)
               << ", \"mate_search\": " << (Opt.MateSearch ? 1 : 0) << ", \"mates_found\": " << S.MatesFound
+              << ", \"dfpn_nodes\": " << Opt.DfpnNodes << ", \"dfpn_mates\": " << S.DfpnMates
+              << ", \"dfpn_nodes_per_move\": " << (S.Moves ? (double)S.DfpnNodes / S.Moves : 0.0)
+              << ", \"teacher_records\": " << S.TeacherRecords
               << ", \"digest\": " << Digest << "}" << std::endl;
     return 0;
 }

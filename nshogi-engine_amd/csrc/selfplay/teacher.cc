@@ -1,0 +1,60 @@
+// teacher.cc -- see teacher.h
+#include "teacher.h"
+
+#include <cstring>
+#include <stdexcept>
+
+namespace nshogi {
+namespace engine {
+namespace selfplay {
+
+TeacherWriter::TeacherWriter(const std::string& Path) {
+    Out = std::fopen(Path.c_str(), "wb");
+    if (Out == nullptr) throw std::runtime_error("cannot open teacher file " + Path);
+    const uint32_t Header[4] = {0x5447534eu /* "NSGT" */, 1u, (uint32_t)sizeof(TeacherRecord), 0u};
+    std::fwrite(Header, sizeof(Header), 1, Out);
+}
+
+TeacherWriter::~TeacherWriter() {
+    if (Out) std::fclose(Out);
+}
+
+std::size_t TeacherWriter::saveGame(const std::vector<uint32_t>& Moves, const std::vector<uint8_t>& FullSearch,
+                                    const shogi::StateConfig& Config, shogi::Color Winner) {
+    std::vector<TeacherRecord> Buf;
+    shogi::State Replay;
+    for (std::size_t Ply = 0; Ply < Moves.size(); ++Ply) {
+        shogi::Move M;
+        M.V = Moves[Ply];
+        if (Ply < FullSearch.size() && FullSearch[Ply]) { // saveworker.cc:172-178
+            TeacherRecord R;
+            std::memset(&R, 0, sizeof(R));
+            for (int Sq = 0; Sq < shogi::NumSquares; ++Sq) R.Board[Sq] = Replay.pieceOn(Sq);
+            for (int C = 0; C < 2; ++C)
+                for (int T = 0; T < shogi::NumHandTypes; ++T)
+                    R.Hands[C][T] = (uint8_t)Replay.hand((shogi::Color)C, (shogi::PieceType)(T + 1));
+            R.SideToMove = (uint8_t)Replay.sideToMove();
+            R.Winner = (uint8_t)Winner;
+            R.Declare27 = Config.Declare27 ? 1 : 0;
+            R.Ply = (uint16_t)Replay.ply();
+            R.NextMove16 = M.move16();
+            R.MaxPly = Config.MaxPly;
+            R.BlackDrawValue = Config.BlackDrawValue;
+            R.WhiteDrawValue = Config.WhiteDrawValue;
+            R.GameLength = (uint16_t)Moves.size();
+            Buf.push_back(R);
+        }
+        Replay.doMove(M);
+    }
+    if (!Buf.empty()) {
+        std::lock_guard<std::mutex> Lock(Mutex);
+        if (std::fwrite(Buf.data(), sizeof(TeacherRecord), Buf.size(), Out) != Buf.size())
+            throw std::runtime_error("short write to the teacher file");
+        Records += Buf.size();
+    }
+    return Buf.size();
+}
+
+} // namespace selfplay
+} // namespace engine
+} // namespace nshogi

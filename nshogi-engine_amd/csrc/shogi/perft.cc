@@ -4,6 +4,9 @@
 //   crosscheck <games> <seed>       random playouts: fast generator == slow generator,
 //                                   do/undo restores the hash, sfen round-trips
 #include "shogi.h"
+#include "dfpn.h"
+
+#include <functional>
 
 #include <algorithm>
 #include <cstdio>
@@ -131,6 +134,103 @@ int main(int Argc, char** Argv) {
         std::cout << "positions " << Pos.size() << " mates " << Found << " findMate(3) "
                   << std::chrono::duration<double, std::nano>(T1 - T0).count() / Pos.size() << " ns, generateLegalMoves "
                   << std::chrono::duration<double, std::nano>(T2 - T1).count() / Pos.size() << " ns (" << (double)Total / Pos.size() << " moves)" << std::endl;
+        return 0;
+    }
+    if (Cmd == "dfpn") { // dfpn <nodes> <sfen>: mating move (or "none"), nodes used, principal variation
+        State S = State::fromSfen(joinArgs(Argc, Argv, 3));
+        DfpnSolver Solver;
+        const Move M = Solver.solve(S, (uint64_t)std::atoll(Argv[2]));
+        std::cout << (M.isNone() ? std::string("none") : moveToUsi(M)) << " nodes " << Solver.nodes() << " pv";
+        for (const Move& P : Solver.pv()) std::cout << " " << moveToUsi(P);
+        std::cout << std::endl;
+        return 0;
+    }
+    if (Cmd == "dfpncheck") { // dfpncheck <games> <seed> <nodes>: soundness and shallow completeness on random playouts
+        const int Games = std::atoi(Argv[2]);
+        std::mt19937_64 Rng((uint64_t)std::atoll(Argv[3]));
+        const uint64_t Budget = (uint64_t)std::atoll(Argv[4]);
+        DfpnSolver Solver, Sub;
+        uint64_t Positions = 0, Mate3 = 0, Found = 0, Deeper = 0, Verified = 0, GaveUp = 0, NodesSum = 0, MaxPv = 0;
+        // Every defence must again lose to a proven move, down to positions without a reply.
+        // Returns 1 verified, 0 refuted, -1 out of verification budget.
+        uint64_t Work = 0;
+        std::function<int(State&, Move, int)> Verify = [&](State& S, Move A, int Depth) -> int {
+            if (++Work > 20000 || Depth > 60) return -1;
+            S.doMove(A);
+            int Result = 1;
+            if (!S.inCheck()) Result = 0;
+            MoveList R;
+            S.generateLegalMoves(R);
+            for (int I = 0; I < R.size() && Result == 1; ++I) {
+                S.doMove(R[I]);
+                const Move Next = Sub.solve(S, Budget);
+                if (Next.isNone()) Result = Sub.nodes() >= Budget ? -1 : 0;
+                else Result = Verify(S, Next, Depth + 2);
+                S.undoMove();
+            }
+            S.undoMove();
+            return Result;
+        };
+        for (int G = 0; G < Games; ++G) {
+            State S;
+            for (int Ply = 0; Ply < 300; ++Ply) {
+                MoveList L;
+                S.generateLegalMoves(L);
+                if (L.size() == 0 || S.repetitionStatus(true) != NoRepetition) break;
+                ++Positions;
+                const uint64_t H = S.hash();
+                const bool Shallow = !S.findMate(3).isNone();
+                const Move A = Solver.solve(S, Budget);
+                NodesSum += Solver.nodes();
+                if (S.hash() != H) { std::cout << "solve did not restore the position " << S.toSfen() << std::endl; return 1; }
+                Mate3 += Shallow;
+                if (Shallow && A.isNone() && Solver.nodes() < Budget) {
+                    std::cout << "dfpn disproved a position with a mate in three " << S.toSfen() << std::endl;
+                    return 1;
+                }
+                if (!A.isNone()) {
+                    ++Found;
+                    if (!Shallow) ++Deeper;
+                    MaxPv = std::max<uint64_t>(MaxPv, Solver.pv().size());
+                    Work = 0;
+                    const int V = Verify(S, A, 1);
+                    if (V == 0) { std::cout << "unsound mate " << moveToUsi(A) << " at " << S.toSfen() << std::endl; return 1; }
+                    if (V == 1) ++Verified; else ++GaveUp;
+                }
+                S.doMove(L[(int)(Rng() % (uint64_t)L.size())]);
+            }
+        }
+        std::cout << "positions " << Positions << " mate3 " << Mate3 << " dfpn " << Found << " deeper " << Deeper
+                  << " verified " << Verified << " gaveup " << GaveUp << " maxpv " << MaxPv << " avg_nodes "
+                  << (double)NodesSum / (double)std::max<uint64_t>(Positions, 1) << " ok" << std::endl;
+        return 0;
+    }
+    if (Cmd == "dfpnbench") { // dfpnbench <games> <seed> <nodes>: ns per node expansion and per solve on random playouts
+        const int Games = std::atoi(Argv[2]);
+        std::mt19937_64 Rng((uint64_t)std::atoll(Argv[3]));
+        const uint64_t Budget = (uint64_t)std::atoll(Argv[4]);
+        std::vector<State> Pos;
+        for (int G = 0; G < Games; ++G) {
+            State S;
+            for (int Ply = 0; Ply < 200; ++Ply) {
+                MoveList L;
+                S.generateLegalMoves(L);
+                if (L.size() == 0 || S.repetitionStatus(true) != NoRepetition) break;
+                Pos.push_back(S);
+                S.doMove(L[(int)(Rng() % (uint64_t)L.size())]);
+            }
+        }
+        DfpnSolver Solver;
+        uint64_t Nodes = 0, Found = 0, Exhausted = 0;
+        auto T0 = std::chrono::steady_clock::now();
+        for (State& S : Pos) {
+            Found += !Solver.solve(S, Budget).isNone();
+            Nodes += Solver.nodes();
+            Exhausted += Solver.nodes() >= Budget;
+        }
+        const double Ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - T0).count();
+        std::cout << "positions " << Pos.size() << " mates " << Found << " budget_exhausted " << Exhausted << " nodes/solve "
+                  << (double)Nodes / Pos.size() << " ns/node " << Ns / Nodes << " us/solve " << Ns / 1000.0 / Pos.size() << std::endl;
         return 0;
     }
     if (Cmd == "moves") {

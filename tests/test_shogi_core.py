@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -87,6 +88,22 @@ def test_mate_search_agrees_with_exhaustive_on_random_playouts():
     assert out.strip().endswith("ok") and "mate3" in out
 
 
+def test_dfpn_solver_is_sound_and_finds_shallow_mates():
+    """DfpnSolver (role of libnshogi's solver::dfpn::Solver at selfplay/worker.cc:516-524) on
+    random-playout positions: never disproves a position findMate(3) solves, restores the position,
+    and every mate it returns is replayed against every defence down to real checkmates."""
+    out = run("perft", "dfpncheck", 10, 7, 20000).split()
+    assert out[-1] == "ok"
+    stats = dict(zip(out[0:-1:2], out[1:-1:2]))
+    assert int(stats["dfpn"]) >= int(stats["mate3"]) > 0 and int(stats["deeper"]) > 0
+    assert int(stats["verified"]) > 0.9 * int(stats["dfpn"])
+    # the mate-in-three sample of the test above, through the solver
+    sfen = run("perft", "matesample", 3).strip()
+    a = run("perft", "mate", 3, sfen).split()[0]
+    d = run("perft", "dfpn", 100000, sfen).split()
+    assert d[0] != "none" and a != "none" and len(d[d.index("pv") + 1:]) >= 3
+
+
 def test_selfplay_cpu_random_executor_reproducible():
     """EXECUTOR=random self-play (BASELINE config 1 plumbing): finishes games and is
     bit-reproducible under a fixed seed; a different seed plays different games."""
@@ -98,6 +115,49 @@ def test_selfplay_cpu_random_executor_reproducible():
     assert a["games_finished"] >= 6 and a["digest"] == b["digest"] and a["moves"] == b["moves"]
     assert c["digest"] != a["digest"]
     assert a["black"] + a["white"] + a["draw"] == a["games_finished"]
+
+
+def test_selfplay_teacher_records(nsg, tmp_path):
+    """--teacher (role of SaveWorker::save, saveworker.cc:160-182): one record per full-search
+    ply of every finished game.  Checked here: the count reported, 40 pieces in every position,
+    ply parity, consistent game-level fields, and -- with every search a full search -- that
+    applying a record's move yields exactly the next record's position, from the initial position
+    to the end of each game."""
+    path = str(tmp_path / "t.nsgt")
+    out = json.loads(run("selfplay", "--executor", "random", "--threads", "2", "--games-per-group", "3",
+                         "--playouts", "24", "--max-games", "4", "--seed", 11, "--full-search-ratio", "1.0",
+                         "--teacher", path))
+    rec = nsg.teacher.load(path)
+    assert len(rec) == out["teacher_records"] > 0
+    assert np.all(rec["winner"] <= 2) and np.all(rec["side_to_move"] == rec["ply"] % 2)
+    on_board = (rec["board"] != 0).sum(axis=1) + rec["hands"].reshape(len(rec), -1).sum(axis=1)
+    assert np.all(on_board == 40)
+    assert np.all(((rec["board"] & 15) == 8).sum(axis=1) == 2)  # both kings
+    # games are written whole and in ply order: a new game starts where the ply does not grow.
+    # Positions with a single legal reply are never "full" searches (worker.cc:171-176), so a few
+    # plies may be missing; everything else must be there at ratio 1.0.
+    cuts = [0] + [i for i in range(1, len(rec)) if rec["ply"][i] <= rec["ply"][i - 1]] + [len(rec)]
+    assert len(cuts) - 1 == out["games_finished"]
+    assert len(rec) > 0.9 * sum(int(rec["game_length"][c]) for c in cuts[:-1])
+    chained = 0
+    for s, e in zip(cuts[:-1], cuts[1:]):
+        g = rec[s:e]
+        assert g["ply"][0] == 0 and np.array_equal(g["board"][0], rec["board"][0])  # all from the initial position
+        assert len(set(g["winner"])) == 1 and len(set(g["max_ply"])) == 1 and len(set(g["game_length"])) == 1
+        assert np.all(g["ply"] < g["game_length"])
+        assert np.all(g["black_draw_value"] + g["white_draw_value"] == np.float32(1.0))
+        for k in range(len(g) - 1):
+            if g["ply"][k + 1] != g["ply"][k] + 1:
+                continue
+            b, h = nsg.teacher.apply_move(g["board"][k], g["hands"][k], int(g["side_to_move"][k]), int(g["next_move16"][k]))
+            assert np.array_equal(b, g["board"][k + 1]) and np.array_equal(h, g["hands"][k + 1])
+            chained += 1
+    assert chained > 0.8 * len(rec)
+    # the default ratio writes only a subset
+    out2 = json.loads(run("selfplay", "--executor", "random", "--threads", "1", "--games-per-group", "3",
+                          "--playouts", "24", "--max-games", "2", "--seed", 11, "--teacher", path))
+    rec2 = nsg.teacher.load(path)
+    assert 0 < len(rec2) == out2["teacher_records"] < out2["moves"]
 
 
 def test_selfplay_gumbel_mode_cpu():
