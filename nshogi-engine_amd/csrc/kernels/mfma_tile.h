@@ -142,6 +142,21 @@ __device__ __forceinline__ void splitF16(float v, uint16_t& hi, uint16_t& lo) {
     hi = __builtin_bit_cast(uint16_t, h);
     lo = __builtin_bit_cast(uint16_t, l);
 }
+// Two values at once: range clamp fused with the ReLU floor (v_med3 takes its inputs unquieted),
+// packed conversions (v_cvt_pk_f16_f32) and a packed subtraction.  floorV = 0 (ReLU) or -65000.
+__device__ __forceinline__ void splitF16Pair(float a, float b, float floorV, uint32_t& hi, uint32_t& lo) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 x = {__builtin_amdgcn_fmed3f(a, floorV, 65000.f), __builtin_amdgcn_fmed3f(b, floorV, 65000.f)};
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+// max(x, 0) for the non-NaN values the network produces, as one instruction (fmaxf first quiets its input)
+__device__ __forceinline__ float reluF(float x) {
+    return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff());
+}
 __device__ __forceinline__ float f16BitsToF32(uint16_t b) {
     return (float)__builtin_bit_cast(_Float16, b);
 }
@@ -742,7 +757,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 }
                 if (A.relu) {
 #pragma unroll
-                    for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    for (int i = 0; i < NFRAG * 4; ++i) v[i] = reluF(v[i]);
                 }
 #pragma unroll
                 for (int j = 0; j < NFRAG; ++j) {
@@ -776,7 +791,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 }
                 if (A.relu) {
 #pragma unroll
-                    for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    for (int i = 0; i < NFRAG * 4; ++i) v[i] = reluF(v[i]);
                 }
 #pragma unroll
                 for (int j = 0; j < NFRAG; ++j) {
@@ -831,6 +846,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         };
         const int lrow = lane / kPPR;   // lane-linear view: row within an instruction
         const int lpc = lane % kPPR;    //                   piece within the row
+        // global addresses = wave-uniform row base (scalar arithmetic) + one per-lane 32-bit offset
+        const unsigned laneOff = (unsigned)lrow * (unsigned)rowBytes + (unsigned)lpc * 16u;
+        const size_t tileOff = (row0 + (size_t)fBase * 16) * rowBytes + sliceOff;
+        const unsigned char* resBase = A.res + tileOff;
+        unsigned char* yBase = A.y + tileOff;
 
         // Most of this wave's residual slice is requested up front (the main loop's operand registers
         // are dead), so the fragment pipeline below does not wait a global round trip per fragment.
@@ -847,7 +867,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     const int m = (fBase + f) * 16 + it * kRPI + lrow;
                     rpre[f][it] = u32x4{0u, 0u, 0u, 0u};
                     if (m < G::kRows)
-                        rpre[f][it] = *reinterpret_cast<const u32x4*>(A.res + (row0 + m) * rowBytes + sliceOff + lpc * 16);
+                        rpre[f][it] = *reinterpret_cast<const u32x4*>(resBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff);
                 }
         }
 
@@ -881,7 +901,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                         t = rpre[f < kPreFrags ? f : 0][it];
                     } else {
                         if (m < G::kRows)
-                            t = *reinterpret_cast<const u32x4*>(A.res + (row0 + m) * rowBytes + sliceOff + lpc * 16);
+                            t = *reinterpret_cast<const u32x4*>(resBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff);
                     }
                     *reinterpret_cast<u32x4*>(ebuf + (f % kRegions) * kFragBytes + r * kRowS + lpc * 16) = t;
                 }
@@ -937,11 +957,13 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                             }
                     }
                 }
-                if (A.relu) {
+                // (the split formats fold the ReLU into the range clamp of their encoders below: one v_med3 per value)
+                if (A.relu && !(kM8 || kSplit)) {
 #pragma unroll
-                    for (int i = 0; i < NFRAG * 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    for (int i = 0; i < NFRAG * 4; ++i) v[i] = reluF(v[i]);
                 }
                 u32x4 op[kNP];
+                [[maybe_unused]] const float floorV = A.relu ? 0.f : -65000.f;
                 if constexpr (PREC == kFp32) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -952,11 +974,10 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     for (int k = 0; k < 2; ++k)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            uint16_t h0, l0, h1, l1;
-                            splitF16(v[k * 8 + 2 * i], h0, l0);
-                            splitF16(v[k * 8 + 2 * i + 1], h1, l1);
-                            op[k][i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                            op[2 + k][i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                            uint32_t h2, l2;
+                            splitF16Pair(v[k * 8 + 2 * i], v[k * 8 + 2 * i + 1], floorV, h2, l2);
+                            op[k][i] = h2;
+                            op[2 + k][i] = l2;
                         }
                 } else if constexpr (kM8) {
                     if (outX3) {
@@ -964,30 +985,35 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                         for (int k = 0; k < 2; ++k)
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                uint16_t h0, l0, h1, l1;
-                                splitF16(v[k * 8 + 2 * i], h0, l0);
-                                splitF16(v[k * 8 + 2 * i + 1], h1, l1);
-                                op[k][i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                                op[2 + k][i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
-                            }
-                    } else {
-                        float hf[16], lf[16];
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) {
-                            const float x = fminf(fmaxf(v[c], -65000.f), 65000.f);
-                            const _Float16 h = (_Float16)x;
-                            const uint32_t hb = __builtin_bit_cast(uint16_t, h);
-                            if (c & 1) op[c >> 3][(c & 7) >> 1] |= hb << 16;
-                            else op[c >> 3][(c & 7) >> 1] = hb;
-                            hf[c] = __builtin_amdgcn_fmed3f((float)h, -448.f, 448.f);
-                            lf[c] = __builtin_amdgcn_fmed3f((x - (float)h) * (float)(1 << kM8LoShift), -448.f, 448.f);
+                            uint32_t h2, l2;
+                            splitF16Pair(v[k * 8 + 2 * i], v[k * 8 + 2 * i + 1], floorV, h2, l2);
+                            op[k][i] = h2;
+                            op[2 + k][i] = l2;
                         }
+                    } else {
+                        // two values per instruction where the ISA has a packed form (v_cvt_pk_f16_f32,
+                        // v_pk_add_f32, v_pk_mul_f32); v_med3 needs no NaN-quieting of its inputs
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                         for (int d = 0; d < 4; ++d) {
-                            int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[4 * d], hf[4 * d + 1], 0, false);
-                            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[4 * d + 2], hf[4 * d + 3], h8, true);
-                            int l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[4 * d], lf[4 * d + 1], 0, false);
-                            l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[4 * d + 2], lf[4 * d + 3], l8, true);
+                            f32x2 hf[2], lf[2];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const int c = 4 * d + 2 * q;
+                                const f32x2 x = {__builtin_amdgcn_fmed3f(v[c], floorV, 65000.f),
+                                                 __builtin_amdgcn_fmed3f(v[c + 1], floorV, 65000.f)};
+                                const f16x2 h = __builtin_convertvector(x, f16x2);
+                                op[c >> 3][(c & 7) >> 1] = __builtin_bit_cast(uint32_t, h);
+                                const f32x2 hx = __builtin_convertvector(h, f32x2);
+                                const f32x2 lx = (x - hx) * (float)(1 << kM8LoShift);
+                                hf[q] = f32x2{__builtin_amdgcn_fmed3f(hx[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(hx[1], -448.f, 448.f)};
+                                lf[q] = f32x2{__builtin_amdgcn_fmed3f(lx[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(lx[1], -448.f, 448.f)};
+                            }
+                            int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[0][0], hf[0][1], 0, false);
+                            h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hf[1][0], hf[1][1], h8, true);
+                            int l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[0][0], lf[0][1], 0, false);
+                            l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lf[1][0], lf[1][1], l8, true);
                             op[2][d] = (uint32_t)h8;
                             op[3][d] = (uint32_t)l8;
                         }
@@ -1007,7 +1033,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 for (int it = 0; it < kIPF; ++it) {
                     const int m = (fBase + f) * 16 + it * kRPI + lrow;
                     if (m < G::kRows)
-                        *reinterpret_cast<u32x4*>(A.y + (row0 + m) * rowBytes + sliceOff + lpc * 16) = tt[it];
+                        *reinterpret_cast<u32x4*>(yBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff) = tt[it];
                 }
             }
         }
@@ -1038,7 +1064,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             for (int i = 0; i < NFRAG * 4; ++i) {
                 const int n = cbase + i;
                 if (n < vc) {
-                    const float r = fmaxf(v[i], 0.f);
+                    const float r = reluF(v[i]);
                     const size_t e = (size_t)b * A.vfeatStride + (size_t)sq * vc + n;
                     if constexpr (kSplit) {
                         // dense-layer input row: K index kk = sq*vc + n, same chunked hi/lo layout
