@@ -219,7 +219,18 @@ struct nsg_evaluator {
     nsg::ConvTuning tuning;   // NSG_CONV_* overrides, read at creation
     nsg::ConvPlan lastPlan{0, 0, 0};
     int lastChains = 0;
-    int chainDelayUs = 0;     // NSG_CHAIN_DELAY_US: start chain c that much later (x c)
+    // Staggered chains: chain c starts c/chains of a conv layer's duration after chain 0, so one
+    // chain's memory bursts (tile loads, residual reads, output stores) fall into the other's matrix
+    // phase instead of colliding with its bursts.  The layer time is measured on the first chained
+    // forward of a given shape (HIP events around chain 0's residual trunk); results do not depend on it.
+    // Off by default: measured +2.5 %, +2 % and +0.3 % at B = 512 (20x256, kF16m8) on three boxes, -2.4 % on
+    // 10x192 and nothing below a full chip -- too fragile to be the default.
+    int chainDelayUs = 0;     // NSG_CHAIN_DELAY_US: 0 = no stagger, -1 = measured layer time / chains, > 0 = fixed
+    hipEvent_t calibEv[2] = {};
+    bool calibPending = false;
+    int calibKey = -1;        // launch shape (rounds of workgroups per chain launch, chains) the measurement belongs to
+    int calibPendingKey = -1;
+    float calibLayerUs = 0.f;
 
     // profiling
     bool profile = false;
@@ -402,8 +413,20 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // start while chain B is still in layer l.  The partly filled last round of
     // workgroups of one chain's launch is topped up by the other chain's launch instead
     // of idling the chip (B=640: 82.7k -> 111.6k evals/s; B=1024: 113.8k -> 119.7k).
-    const int minBatch = ev->chainMinBatch > 0 ? ev->chainMinBatch : 2 * ev->prop.multiProcessorCount + 1;
-    int chains = (B >= minBatch && plan.nb == 2) ? ev->numChains : 1;
+    // With NSG_CHAIN_DELAY_US set, two staggered chains (below) also run when all tiles are resident at
+    // once on more than half the chip (B = 512 on 256 CUs; not the f32 kernel, which is matrix-bound at
+    // 0.85 of its peak and loses 2 %).  With more tiles than CUs the chains compete for CUs and topping-up
+    // matters more than phase: those always run unstaggered (staggered B = 640 loses 2 %).
+    const int cus = ev->prop.multiProcessorCount;
+    const int tiles = ((B + 1) / 2) * std::max(1, ev->F / (plan.nwaves * plan.nfrag * 16)); // of a 2-board plan
+    const bool oneRound = tiles <= cus;
+    int chains = 1;
+    if (plan.nb == 2) {
+        if (ev->chainMinBatch > 0) chains = B >= ev->chainMinBatch ? ev->numChains : 1;
+        else if (!oneRound) chains = ev->numChains;
+        else if (2 * tiles > cus && ev->chainDelayUs != 0 && ev->prec != nsg::kFp32) chains = std::min(ev->numChains, 2);
+    }
+    const bool stagger = oneRound && chains > 1;
     if (ev->useTrunkKernel && nsg::canRunTrunk(ev->F, plan)) chains = 1;
     const int per = ((B + chains - 1) / chains + 1) / 2 * 2; // boards per chain, whole 2-board tiles
     ev->lastPlan = plan;
@@ -432,6 +455,30 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         int rc = enqueueChain(ev, 0, B, plan, s, true, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
         if (rc) return rc;
     } else {
+        // stagger: measured layer time / chains (first forward of a launch shape runs unstaggered and is timed)
+        int delayUs = (stagger || ev->chainDelayUs > 0) ? ev->chainDelayUs : 0;
+        bool calibrate = false;
+        if (delayUs < 0) {
+            if (ev->calibPending) { // the previous forward has been awaited: its events are complete
+                float ms = 0.f;
+                if (hipEventSynchronize(ev->calibEv[1]) == hipSuccess &&
+                    hipEventElapsedTime(&ms, ev->calibEv[0], ev->calibEv[1]) == hipSuccess && ev->blocks > 0) {
+                    ev->calibLayerUs = ms * 1000.f / (float)(2 * ev->blocks);
+                    ev->calibKey = ev->calibPendingKey;
+                }
+                ev->calibPending = false;
+            }
+            const int wgPerChain = (per / 2) * std::max(1, ev->F / (plan.nwaves * plan.nfrag * 16));
+            const int rounds = (wgPerChain + ev->prop.multiProcessorCount - 1) / ev->prop.multiProcessorCount;
+            const int key = rounds * 16 + chains;
+            if (key == ev->calibKey && ev->calibLayerUs > 0.f) {
+                delayUs = (int)(ev->calibLayerUs / (float)chains + 0.5f);
+            } else {
+                delayUs = 0;
+                calibrate = ev->blocks > 0;
+                ev->calibPendingKey = key;
+            }
+        }
         NSG_HIP(hipEventRecord(ev->forkEvent, s));
         if (prof) NSG_HIP(hipEventRecord(e[1], s));
         for (int c = 0; c < chains; ++c) {
@@ -440,11 +487,14 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
             if (count <= 0) break;
             hipStream_t cs = (c == 0) ? s : ev->chainStream[c - 1];
             if (c > 0) NSG_HIP(hipStreamWaitEvent(cs, ev->forkEvent, 0));
-            if (c > 0 && ev->chainDelayUs > 0) {
-                hipLaunchKernelGGL(delayKernel, dim3(1), dim3(64), 0, cs, (unsigned long long)ev->chainDelayUs * 100ull * c);
+            if (c > 0 && delayUs > 0) {
+                hipLaunchKernelGGL(delayKernel, dim3(1), dim3(64), 0, cs, (unsigned long long)delayUs * 100ull * c);
             }
-            int rc = enqueueChain(ev, off, count, plan, cs, c == 0);
+            const bool timeIt = calibrate && c == 0;
+            int rc = enqueueChain(ev, off, count, plan, cs, c == 0, timeIt ? ev->calibEv[0] : nullptr,
+                                  timeIt ? ev->calibEv[1] : nullptr);
             if (rc) return rc;
+            if (timeIt) ev->calibPending = true;
             if (c > 0) {
                 NSG_HIP(hipEventRecord(ev->joinEvent[c - 1], cs));
                 NSG_HIP(hipStreamWaitEvent(s, ev->joinEvent[c - 1], 0));
@@ -508,7 +558,8 @@ int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator**
         if (v >= 1 && v <= nsg_evaluator::kMaxChains) ev->numChains = v;
     }
     ev->tuning = nsg::readConvTuning();
-    if (const char* e2 = getenv("NSG_CHAIN_DELAY_US")) ev->chainDelayUs = std::max(0, atoi(e2));
+    for (auto& ce : ev->calibEv) NSG_HIP(hipEventCreate(&ce));
+    if (const char* e2 = getenv("NSG_CHAIN_DELAY_US")) ev->chainDelayUs = std::max(-1, atoi(e2));
     if (const char* e2 = getenv("NSG_CHAIN_MIN_BATCH")) ev->chainMinBatch = std::max(2, atoi(e2));
     *out = ev.release();
     return NSG_OK;
@@ -526,6 +577,8 @@ int nsg_destroy(nsg_evaluator* ev) {
     if (ev->forkEvent) (void)hipEventDestroy(ev->forkEvent);
     for (auto je : ev->joinEvent)
         if (je) (void)hipEventDestroy(je);
+    for (auto ce : ev->calibEv)
+        if (ce) (void)hipEventDestroy(ce);
     if (ev->stream) (void)hipStreamDestroy(ev->stream);
     delete ev;
     return NSG_OK;
@@ -664,6 +717,8 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
         ev->useTrunkKernel = (env && env[0] == '1');
     }
     NSG_HIP(hipDeviceSynchronize());
+    ev->calibKey = -1; // a new network: re-measure the layer time for the chain stagger
+    ev->calibPending = false;
     ev->loaded = true;
     return NSG_OK;
 }

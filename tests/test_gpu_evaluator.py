@@ -199,6 +199,30 @@ def test_f16m8_ragged_batch_sizes_against_f16x3(nsg):
     assert ("f16m8", 1, 1) in seen and ("f16m8", 2, 1) in seen and ("f16m8", 2, 2) in seen, seen
 
 
+@pytest.mark.parametrize("precision", ["f16m8", "f16x3"])
+def test_staggered_chains_bit_identical(nsg, monkeypatch, precision):
+    """NSG_CHAIN_DELAY_US=-1 (off by default): with all tiles resident at once on more than half the
+    CUs (batch = 2 x CUs) the forward runs as two chains, the second started a measured fraction of
+    a layer later.  The first forward measures the layer time unstaggered, the following ones are
+    staggered; every one is bit-identical to a single chain."""
+    monkeypatch.setenv("NSG_CHAIN_DELAY_US", "-1")
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    batch = 2 * cus
+    bb = nsg.synth.random_batch(batch, 86, seed=91)
+    ev, _ = make(nsg, 2, 256, batch, precision=precision, seed=35)
+    outs = [ev.compute_blocking(bb) for _ in range(3)]
+    assert ev.last_plan()["chains"] == 2
+    monkeypatch.setenv("NSG_CHAINS", "1")
+    ev1, _ = make(nsg, 2, 256, batch, precision=precision, seed=35)
+    ref = ev1.compute_blocking(bb)
+    assert ev1.last_plan()["chains"] == 1
+    for o in outs:
+        for x, y in zip(o, ref):
+            np.testing.assert_array_equal(x, y)
+
+
 def test_f16m8_persistent_trunk_kernel_bit_identical(nsg, monkeypatch):
     """NSG_TRUNK_KERNEL=1: all 3x3 layers in one launch (a workgroup owns its boards through
     every layer, no grid barrier).  Same arithmetic, so bit-identical to per-layer launches."""
