@@ -852,6 +852,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         const unsigned char* resBase = A.res + tileOff;
         unsigned char* yBase = A.y + tileOff;
 
+#ifdef NSG_EXP_HOTRES
+#define NSG_RES_FRAG(F) 0 /* timing-only build: every residual fragment re-reads the first one (cache hits; results are wrong) */
+#else
+#define NSG_RES_FRAG(F) (F)
+#endif
         // Most of this wave's residual slice is requested up front (the main loop's operand registers
         // are dead), so the fragment pipeline below does not wait a global round trip per fragment.
         // (only the first kPreFrags fragments: with all eleven the epilogue spills; kernels capped at
@@ -867,7 +872,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     const int m = (fBase + f) * 16 + it * kRPI + lrow;
                     rpre[f][it] = u32x4{0u, 0u, 0u, 0u};
                     if (m < G::kRows)
-                        rpre[f][it] = *reinterpret_cast<const u32x4*>(resBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff);
+                        rpre[f][it] = *reinterpret_cast<const u32x4*>(resBase + (size_t)(NSG_RES_FRAG(f) * 16 + it * kRPI) * rowBytes + laneOff);
                 }
         }
 
@@ -901,7 +906,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                         t = rpre[f < kPreFrags ? f : 0][it];
                     } else {
                         if (m < G::kRows)
-                            t = *reinterpret_cast<const u32x4*>(resBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff);
+                            t = *reinterpret_cast<const u32x4*>(resBase + (size_t)(NSG_RES_FRAG(f) * 16 + it * kRPI) * rowBytes + laneOff);
                     }
                     *reinterpret_cast<u32x4*>(ebuf + (f % kRegions) * kFragBytes + r * kRowS + lpc * 16) = t;
                 }
