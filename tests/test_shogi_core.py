@@ -97,6 +97,11 @@ def test_dfpn_solver_is_sound_and_finds_shallow_mates():
     stats = dict(zip(out[0:-1:2], out[1:-1:2]))
     assert int(stats["dfpn"]) >= int(stats["mate3"]) > 0 and int(stats["deeper"]) > 0
     assert int(stats["verified"]) > 0.9 * int(stats["dfpn"])
+    # hand-made cases: a gold dropped in front of the king on a square the pawn guards is mate;
+    # without the pawn the bare gold never mates (disproved, not just out of budget)
+    assert run("perft", "dfpn", 1000, "4k4/9/4P4/9/9/9/9/9/4K4 b G 1").split()[:1] == ["G*5b"]
+    lone = run("perft", "dfpn", 100000, "4k4/9/9/9/9/9/9/9/4K4 b G 1").split()
+    assert lone[0] == "none" and int(lone[2]) < 1000
     # the mate-in-three sample of the test above, through the solver
     sfen = run("perft", "matesample", 3).strip()
     a = run("perft", "mate", 3, sfen).split()[0]
