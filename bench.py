@@ -170,7 +170,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # (NSG_BENCH_FORCE_DIST=1: take the multi-rank code path -- RCCL weight broadcast, reductions -- with one rank,
+    # to rehearse it on a one-GPU box)
+    distributed = world > 1 or os.environ.get("NSG_BENCH_FORCE_DIST") == "1"
     if distributed:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

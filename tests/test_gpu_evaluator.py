@@ -149,6 +149,24 @@ def test_f16m8_small_batches_run_as_f16x3(nsg, oracle):
     check((p[idx], v[idx], d[idx]), net.evaluate(bb[idx]), TOL)
 
 
+def test_load_device_blob_matches_load_memory(nsg):
+    """nsg_load_device_blob (the weight blob already in HBM, e.g. after the RCCL broadcast of
+    bench.py / dist.broadcast_blob): same network as nsg_load_memory, bit for bit."""
+    import torch
+    w = nsg.weights.make_random(2, 128, seed=71, bn="random")
+    blob = nsg.weights.to_blob(w)
+    bb = nsg.synth.random_batch(9, 86, seed=72)
+    a = nsg.Evaluator(0, 16, 86, precision="f16x3"); a.load_memory(blob)
+    dev = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    b = nsg.Evaluator(0, 16, 86, precision="f16x3"); b.load_device_blob(dev.data_ptr(), dev.numel())
+    for x, y in zip(a.compute_blocking(bb), b.compute_blocking(bb)):
+        np.testing.assert_array_equal(x, y)
+    with pytest.raises(nsg.NsgError):
+        b2 = nsg.Evaluator(0, 16, 86)
+        b2.load_device_blob(dev.data_ptr(), 100)  # truncated blob: refused, no crash
+
+
 def test_f16m8_extreme_magnitudes_stay_finite(nsg, oracle, monkeypatch):
     """Activations far beyond the fp8 range of the correction operands (BN gamma 512 in the
     stem: values in the thousands) and weights spanning many binades: the fixed-scale fp8
