@@ -70,6 +70,7 @@ struct ConvPlan {
     int nfrag;   // 16-channel output fragments per wave (fixed at pack time)
     int nwaves;  // waves per workgroup
     int msplit = 1; // wave groups that split the tile's row fragments between them (small one-board tiles: 2)
+    int ksplit = 1; // kF16m8 one-board tiles: waves of a channel group that split the input-channel chunk pairs between them
 };
 constexpr int kNfrag = 4; // every packed tensor uses 4 fragments (64 channels) per wave
 

@@ -238,9 +238,18 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 // 1/MS of the tile's row fragments for NWAVES/MS channel slices, instead of every wave reading every
 // row fragment -- a one-fragment-per-wave tile is LDS-bandwidth-bound, and two fragments per wave on
 // half the rows is the same work per wave for half the LDS reads.
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1>
+// KS (K split, kF16m8 one-board tiles at mid batches): the waves of a channel group each take 1/KS of the
+// input-channel chunk pairs for ALL row fragments and sum their accumulators through LDS at the end.
+// A row split makes every wave of the group stream the group's whole weight set through the L1 (64 B/clk
+// per CU: 2.4 MB = 17 us per layer, more than the MFMAs of a one-board tile take); the K split streams
+// it once.  All 2*KS*... chunk tiles of the board are resident in LDS at once (eight image buffers for
+// 256 channels), so the loop has no staging and no barriers.
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1>
 __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
-    using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? 4 : 2)>;
+    using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? (KS > 1 ? 8 : 4) : 2)>;
+    static_assert(KS == 1 || (PREC == kF16m8 && MODE == kConv && SIZE == 1 && MS == 1 && NWAVES % KS == 0 &&
+                              G::kMF % KS == 0),
+                  "K split: kF16m8 one-board conv tiles");
     const bool hasRes = (RES == 1) || (RES == 2 && A.res != nullptr);
     NSG_STAMP(0);
     constexpr bool kM8 = (PREC == kF16m8);
@@ -271,7 +280,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         nkc = per;
     }
     const int nft = A.cout / 16;
-    const int waveGroup = (blockIdx.y * NWAVES + wave) / MS; // group of NFRAG channel fragments
+    const int waveGroup = (blockIdx.y * NWAVES + wave) / (MS * KS); // group of NFRAG channel fragments
     const int fBase = (MS > 1) ? (wave % MS) * kMFw : 0;     // first row fragment of this wave
     // kConv buffers are sized for whole workgroups; flat modes clamp rows.
     const size_t lastRow = G::kBoards ? ~(size_t)0 : (size_t)(A.totalRows - 1);
@@ -367,7 +376,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #else
         const size_t rs = (size_t)nft * 64; // one record set
 #endif
-        const u32x4* wc = A.w + lane;
+        constexpr bool kStage = (KS == 1); // KS > 1: every chunk tile is resident, nothing is staged in the loop
+        const int kpart = (KS > 1) ? wave % KS : 0; // this wave's share of the chunk pairs
+        const int npairs = nkc / 2 / KS; // pairs this wave runs (the host pads the input channels to whole pairs)
+        const int pair0 = kpart * npairs;  // K split: a contiguous range of the pairs
+        const u32x4* wc = A.w + lane + (size_t)pair0 * Q::kRecPair * rs;
         const size_t wg4 = (size_t)waveGroup * NFRAG * 64;  // this wave's records inside a main set
         const size_t wg8 = wg4 * 2;                         //                          an MX pair of sets
         u32x4 w4[3][NFRAG];
@@ -377,6 +390,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
             for (int j = 0; j < NFRAG; ++j) w4[o][j] = wc[Q::recOff(Q::slabOfMain(o)) * rs + wg4 + j * 64];
 
+        if constexpr (kStage) {
         // first pair's tiles: both requested up front (the loop's operand registers are not live yet)
         u32x4 st1[G::kItems];
         NSG_STAGE_LOAD(0)
@@ -393,6 +407,30 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         for (int k = 0; k < G::kItems; ++k)
             *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? G::kBuf : 0) + dstOff[k]) = st1[k];
         __syncthreads();
+        } else {
+            // every chunk of the board (at most eight) in one go
+            constexpr int kChunks = 8;
+            u32x4 stAll[kChunks][G::kItems];
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c)
+#pragma unroll
+                for (int k = 0; k < G::kItems; ++k) {
+                    stAll[c][k] = u32x4{0u, 0u, 0u, 0u};
+                    if (c < nkc) stAll[c][k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)c * 128);
+                }
+            if (zeroLds) {
+                for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
+                    reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c)
+#pragma unroll
+                for (int k = 0; k < G::kItems; ++k)
+                    if (c < nkc) *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? c * G::kBuf : 0) + dstOff[k]) = stAll[c][k];
+            __syncthreads();
+        }
         NSG_STAMP(1);
 
         u32x4 aw[kWin][2];
@@ -411,14 +449,16 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     b_ + Q::half(s_) * G::kBuf + abase[f_] + tapOff(Q::tap(s_)));                 \
             }                                                                                     \
         }
+        const unsigned char* first = kStage ? smem : smem + (size_t)(2 * pair0) * G::kBuf;
 #pragma unroll
-        for (int q = 0; q < kD; ++q) NSG_M8_REQ(q, smem, smem)
+        for (int q = 0; q < kD; ++q) NSG_M8_REQ(q, first, first)
 
-        const int npairs = nkc / 2; // (the host pads the input channels to whole pairs)
         for (int kp = 0; kp < npairs; ++kp) {
-            const unsigned char* abuf = smem + ((2 * kp) & 3) * G::kBuf;
-            const unsigned char* nbuf = smem + ((2 * kp + 2) & 3) * G::kBuf;
-            const int nextA = (kp + 1 < npairs) ? 2 * kp + 2 : 2 * kp; // (last pair: harmless re-load)
+            const unsigned char* abuf = kStage ? smem + ((2 * kp) & 3) * G::kBuf : smem + (size_t)(2 * (pair0 + kp)) * G::kBuf;
+            // (K split, last pair: the look-ahead requests read this pair again, harmlessly)
+            const unsigned char* nbuf = kStage ? smem + ((2 * kp + 2) & 3) * G::kBuf
+                                               : (kp + 1 < npairs ? abuf + 2 * G::kBuf : abuf);
+            [[maybe_unused]] const int nextA = (kp + 1 < npairs) ? 2 * kp + 2 : 2 * kp; // (last pair: harmless re-load)
             NSG_PIN_ACC_AGPR
 #pragma unroll
             for (int s = 0; s < Q::kSlabs; ++s) {
@@ -432,11 +472,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                         A.stamps[2048 + kp * 32 + s] = __builtin_amdgcn_s_memtime();
 #endif
 #if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOWRITE)
-                    if (q == kWriteStepA) { NSG_STAGE_WRITE((2 * kp + 2) & 3) }
-                    if (q == kWriteStepB) { NSG_STAGE_WRITE((2 * kp + 3) & 3) }
+                    if (kStage && q == kWriteStepA) { NSG_STAGE_WRITE((2 * kp + 2) & 3) }
+                    if (kStage && q == kWriteStepB) { NSG_STAGE_WRITE((2 * kp + 3) & 3) }
 #endif
 #if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOBAR)
-                    if (q == kBarStep) __syncthreads(); // publishes the two tiles written above
+                    if (kStage && q == kBarStep) __syncthreads(); // publishes the two tiles written above
 #endif
                     // MX records: two sets.  X0 is requested at the top of the pair (set 0 is free once
                     // the previous pair's last MX slab is done), X_t+1 at the top of X_t.
@@ -457,8 +497,8 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                                 for (int h = 0; h < 2; ++h) w8[t2 & 1][j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
                         }
                     }
-                    const bool loadA = f == 0 && s >= kLoadSlabA && s < kLoadSlabA + kLoadSlabs;
-                    const bool loadB = f == 0 && s >= kLoadSlabB && s < kLoadSlabB + kLoadSlabs;
+                    const bool loadA = kStage && f == 0 && s >= kLoadSlabA && s < kLoadSlabA + kLoadSlabs;
+                    const bool loadB = kStage && f == 0 && s >= kLoadSlabB && s < kLoadSlabB + kLoadSlabs;
 #if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOLOAD)
                     if (loadA || loadB) {
 #pragma unroll
@@ -502,6 +542,30 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         }
 #undef NSG_M8_REQ
         __syncthreads(); // every wave is done reading before the epilogue reuses LDS
+        if constexpr (KS > 1) {
+            // Sum the K parts: every wave publishes its accumulators, then keeps the row fragments
+            // kpart*kMFe .. +kMFe-1 of its channel group, added up in part order (deterministic).
+            constexpr int kMFe = kMFw / KS;
+            u32x4* xb = reinterpret_cast<u32x4*>(smem);
+#pragma unroll
+            for (int f = 0; f < kMFw; ++f)
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j)
+                    xb[((wave * kMFw + f) * NFRAG + j) * 64 + lane] = __builtin_bit_cast(u32x4, acc[f][j]);
+            __syncthreads();
+            const int w0 = wave - kpart; // first wave of this channel group
+#pragma unroll
+            for (int f = 0; f < kMFe; ++f)
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) {
+                    f32x4 sum = __builtin_bit_cast(f32x4, xb[(((w0 + 0) * kMFw + kpart * kMFe + f) * NFRAG + j) * 64 + lane]);
+#pragma unroll
+                    for (int p2 = 1; p2 < KS; ++p2)
+                        sum += __builtin_bit_cast(f32x4, xb[(((w0 + p2) * kMFw + kpart * kMFe + f) * NFRAG + j) * 64 + lane]);
+                    acc[f][j] = sum;
+                }
+            __syncthreads(); // the staging regions of the epilogue overlap the exchange area
+        }
     } else {
     // weight stream: record q = (kc*taps + tap)*2 + s, NFRAG 1-KiB records per wave, held
     // in a register ring (a record is requested whole slabs of MFMAs before its first use,
@@ -809,6 +873,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     }
 
     if constexpr (MODE == kConv && NFRAG == 4) {
+        // (K split: after the exchange a wave owns kMFe of the row fragments, from fBaseE on)
+        constexpr int kMFe = kMFw / KS;
+        const int fBaseE = fBase + ((KS > 1) ? (wave % KS) * kMFe : 0);
         // ---- convolution epilogue, staged through LDS so that every global access is
         // a full-line, lane-linear 16-byte access.  In the MFMA result layout a lane
         // owns 16 channels of ONE row, so a direct store scatters 16-byte pieces over
@@ -848,7 +915,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         const int lpc = lane % kPPR;    //                   piece within the row
         // global addresses = wave-uniform row base (scalar arithmetic) + one per-lane 32-bit offset
         const unsigned laneOff = (unsigned)lrow * (unsigned)rowBytes + (unsigned)lpc * 16u;
-        const size_t tileOff = (row0 + (size_t)fBase * 16) * rowBytes + sliceOff;
+        const size_t tileOff = (row0 + (size_t)fBaseE * 16) * rowBytes + sliceOff;
         const unsigned char* resBase = A.res + tileOff;
         unsigned char* yBase = A.y + tileOff;
 
@@ -862,14 +929,14 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // (only the first kPreFrags fragments: with all eleven the epilogue spills; kernels capped at
         // 256 registers for two waves per SIMD request every fragment one pipeline stage ahead instead)
         constexpr int kPreFrags = (RES != 1 || minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG, PREC>() > 1)
-                                      ? 0 : (kMFw * kIPF <= 32 ? kMFw : 32 / kIPF);
+                                      ? 0 : (kMFe * kIPF <= 32 ? kMFe : 32 / kIPF);
         u32x4 rpre[kPreFrags ? kPreFrags : 1][kIPF];
         if constexpr (kPreFrags > 0) {
 #pragma unroll
             for (int f = 0; f < kPreFrags; ++f)
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
-                    const int m = (fBase + f) * 16 + it * kRPI + lrow;
+                    const int m = (fBaseE + f) * 16 + it * kRPI + lrow;
                     rpre[f][it] = u32x4{0u, 0u, 0u, 0u};
                     if (m < G::kRows)
                         rpre[f][it] = *reinterpret_cast<const u32x4*>(resBase + (size_t)(NSG_RES_FRAG(f) * 16 + it * kRPI) * rowBytes + laneOff);
@@ -888,19 +955,19 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         u32x4 rpp[2][kNP];
         u32x4 tt[kIPF];
 #pragma unroll
-        for (int i = -1; i <= kMFw; ++i) {
+        for (int i = -1; i <= kMFe; ++i) {
             if (i >= 1) { // ---- S(i-1), reads
                 const int f = i - 1;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it)
                     tt[it] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + (it * kRPI + lrow) * kRowS + lpc * 16);
             }
-            if (hasRes && i + 1 < kMFw) { // ---- R(i+1)
+            if (hasRes && i + 1 < kMFe) { // ---- R(i+1)
                 const int f = i + 1;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
                     const int r = it * kRPI + lrow;
-                    const int m = (fBase + f) * 16 + r;
+                    const int m = (fBaseE + f) * 16 + r;
                     u32x4 t = u32x4{0u, 0u, 0u, 0u};
                     if (f < kPreFrags) {
                         t = rpre[f < kPreFrags ? f : 0][it];
@@ -914,7 +981,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 for (int k = 0; k < kNP; ++k)
                     rpp[f & 1][k] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + li * kRowS + pieceOff(k));
             }
-            if (i >= 0 && i < kMFw) { // ---- X(i)
+            if (i >= 0 && i < kMFe) { // ---- X(i)
                 const int f = i;
                 float v[NFRAG * 4];
 #pragma unroll
@@ -1036,7 +1103,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 const int f = i - 1;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
-                    const int m = (fBase + f) * 16 + it * kRPI + lrow;
+                    const int m = (fBaseE + f) * 16 + it * kRPI + lrow;
                     if (m < G::kRows)
                         *reinterpret_cast<u32x4*>(yBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff) = tt[it];
                 }
@@ -1098,10 +1165,10 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     }
 }
 
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES, int MS = 1>
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES, int MS = 1, int KS = 1>
 __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG, PREC>())) void tileKernel(const Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS>(A, smem, true);
+    tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS>(A, smem, true);
 }
 
 // Persistent trunk: one launch runs every 3x3 layer (stem + 2 per residual block)
@@ -1132,14 +1199,18 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
     }
 }
 
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int MS = 1>
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int MS = 1, int KS = 1>
 hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
-    using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? 4 : 2)>;
-    const int gy = a.cout / (NWAVES / MS * NFRAG * 16);
-    if (gy < 1 || gy * (NWAVES / MS) * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
+    using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? (KS > 1 ? 8 : 4) : 2)>;
+    const int gy = a.cout / (NWAVES / (MS * KS) * NFRAG * 16);
+    if (gy < 1 || gy * (NWAVES / (MS * KS)) * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
+    if (KS > 1) { // every chunk tile resident: at most eight, and whole pairs for every K part
+        const int chunks = a.kdim * 4 / 128;
+        if (chunks > 8 || chunks % (2 * KS) != 0) return hipErrorInvalidValue;
+    }
     hipError_t err;
     if (MODE == kConv && a.res) {
-        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, (MODE == kConv), MS>;
+        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, (MODE == kConv), MS, KS>;
         static std::atomic<int> attrDevMask{0}; // per kernel instantiation: devices whose attribute is set
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1150,7 +1221,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
         }
         hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a);
     } else {
-        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false, MS>;
+        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false, MS, KS>;
         static std::atomic<int> attrDevMask{0};
         int dev = 0;
         (void)hipGetDevice(&dev);

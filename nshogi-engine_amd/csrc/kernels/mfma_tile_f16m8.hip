@@ -9,6 +9,8 @@ hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStrea
     const int gx = (batch + p.nb - 1) / p.nb;
     if (p.nfrag != 4) return hipErrorInvalidValue;
     // mid batches: one board per workgroup, two wave groups on three row fragments each
+    // ... or, where all the board's chunk tiles fit in LDS at once, two K halves on all six row fragments
+    if (p.ksplit == 2 && p.nb == 1 && p.nwaves == 4) return launchOne<kF16m8, kConv, 1, 4, 4, 1, 2>(a, gx, s);
     if (p.msplit == 2 && p.nb == 1 && p.nwaves == 4) return launchOne<kF16m8, kConv, 1, 4, 4, 2>(a, gx, s);
 #define NSG_CASE(NB_, NW_) \
     if (p.nb == NB_ && p.nwaves == NW_) return launchOne<kF16m8, kConv, NB_, 4, NW_>(a, gx, s);

@@ -397,6 +397,13 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         const long wgM8 = (long)B * (ev->F / 128);
         if (wgM8 <= cus && wgM8 * 2 > cus) { // (measured: 1.17-1.29 ms for every B in 65..128; kF16x3 plans 1.26-1.54 ms)
             plan.nb = 1; plan.nfrag = 4; plan.nwaves = 4; plan.msplit = 2;
+            // K split instead of the row split where the whole board fits in LDS (<= 256 channels) and both
+            // the stem's and the trunk's chunk pairs halve evenly; NSG_CONV_MSPLIT=2 keeps the row split
+            const int stemChunks = ev->cpad / 32, trunkChunks = ev->F / 32;
+            if (ev->tuning.msplit != 2 && trunkChunks <= 8 && trunkChunks % 4 == 0 && stemChunks % 4 == 0 && stemChunks <= 8) {
+                plan.msplit = 1;
+                plan.ksplit = 2;
+            }
         }
     }
 
@@ -953,6 +960,13 @@ int nsg_get_last_plan(nsg_evaluator* ev, int* nb, int* nfrag, int* nwaves, int* 
     if (nfrag) *nfrag = ev->lastPlan.nfrag;
     if (nwaves) *nwaves = ev->lastPlan.nwaves;
     if (chains) *chains = ev->lastChains;
+    return NSG_OK;
+}
+
+int nsg_get_last_split(nsg_evaluator* ev, int* row_split, int* k_split) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    if (row_split) *row_split = ev->lastPlan.nb ? ev->lastPlan.msplit : 0;
+    if (k_split) *k_split = ev->lastPlan.nb ? ev->lastPlan.ksplit : 0;
     return NSG_OK;
 }
 

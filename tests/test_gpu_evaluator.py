@@ -152,19 +152,64 @@ def test_f16m8_small_batches_run_as_f16x3(nsg, oracle):
 def test_load_device_blob_matches_load_memory(nsg):
     """nsg_load_device_blob (the weight blob already in HBM, e.g. after the RCCL broadcast of
     bench.py / dist.broadcast_blob): same network as nsg_load_memory, bit for bit."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime libnsg.so itself is linked against
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
     w = nsg.weights.make_random(2, 128, seed=71, bn="random")
     blob = nsg.weights.to_blob(w)
     bb = nsg.synth.random_batch(9, 86, seed=72)
     a = nsg.Evaluator(0, 16, 86, precision="f16x3"); a.load_memory(blob)
-    dev = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to("cuda:0")
-    torch.cuda.synchronize()
-    b = nsg.Evaluator(0, 16, 86, precision="f16x3"); b.load_device_blob(dev.data_ptr(), dev.numel())
-    for x, y in zip(a.compute_blocking(bb), b.compute_blocking(bb)):
-        np.testing.assert_array_equal(x, y)
-    with pytest.raises(nsg.NsgError):
-        b2 = nsg.Evaluator(0, 16, 86)
-        b2.load_device_blob(dev.data_ptr(), 100)  # truncated blob: refused, no crash
+    dev = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dev), len(blob)) == 0
+    try:
+        assert hip.hipMemcpy(dev, blob, len(blob), 1) == 0  # hipMemcpyHostToDevice
+        b = nsg.Evaluator(0, 16, 86, precision="f16x3"); b.load_device_blob(dev.value, len(blob))
+        for x, y in zip(a.compute_blocking(bb), b.compute_blocking(bb)):
+            np.testing.assert_array_equal(x, y)
+        with pytest.raises(nsg.NsgError):
+            b2 = nsg.Evaluator(0, 16, 86)
+            b2.load_device_blob(dev.value, 100)  # truncated blob: refused, no crash
+    finally:
+        hip.hipFree(dev)
+
+
+@pytest.mark.parametrize("channels,batch", [(256, 70), (256, 101), (256, 128), (128, 200)])
+def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch):
+    """Mid batches (one workgroup per board and 128 output channels fills more than half the CUs):
+    the two waves of a channel group each run half of the input-channel chunk pairs over all six
+    row fragments, with the whole board resident in eight LDS image buffers, and add their
+    accumulators through LDS.  Against the oracle, against the f16x3 evaluator on every board,
+    and against the row-split plan of the same arithmetic (the f32 sums differ in their last bit by
+    summation order; the fp8 rounding of the low term then turns some of those into differences of the
+    size of the format's own error, ~6e-5 here)."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    wg = batch * (channels // 128)
+    if not (wg <= cus < 2 * wg):
+        pytest.skip("batch range of this plan depends on the CU count")
+    ev, blob = make(nsg, 3, channels, batch, precision="f16m8", seed=63)
+    bb = nsg.synth.random_batch(batch, 86, seed=64, garbage=True)
+    p, v, d = ev.compute_blocking(bb)
+    plan = ev.last_plan()
+    assert plan["trunk_precision"] == "f16m8" and plan["boards_per_group"] == 1 and plan["k_split"] == 2 and plan["row_split"] == 1
+    idx = [0, batch // 2, batch - 1]
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
+    x3, _ = make(nsg, 3, channels, batch, precision="f16x3", seed=63)
+    p3, v3, d3 = x3.compute_blocking(bb)
+    assert float(np.abs(p - p3).max()) < TOL and float(np.abs(v - v3).max()) < TOL and float(np.abs(d - d3).max()) < TOL
+    monkeypatch.setenv("NSG_CONV_MSPLIT", "2")
+    rows, _ = make(nsg, 3, channels, batch, precision="f16m8", seed=63)
+    pr, vr, dr = rows.compute_blocking(bb)
+    plan = rows.last_plan()
+    assert plan["row_split"] == 2 and plan["k_split"] == 1
+    assert float(np.abs(p - pr).max()) < 3e-4 and float(np.abs(v - vr).max()) < 1e-4 and float(np.abs(d - dr).max()) < 1e-4
+    # a forward is deterministic: the same bits again, also at another slot of the batch
+    p2, v2, d2 = ev.compute_blocking(bb[::-1].copy())
+    np.testing.assert_array_equal(p2[::-1], p)
+    np.testing.assert_array_equal(v2[::-1], v)
 
 
 def test_f16m8_extreme_magnitudes_stay_finite(nsg, oracle, monkeypatch):
