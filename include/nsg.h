@@ -203,12 +203,12 @@ int nsg_get_last_plan(nsg_evaluator* ev, int* boards_per_group, int* fragments_p
                       int* waves_per_group, int* chains);
 /* How the waves of one channel group shared a one-board tile in the most recent forward pass:
  * row_split waves took disjoint row fragments (small tiles), or k_split waves took disjoint ranges
- * of the input channels for all rows and summed their accumulators (F16M8 at mid batches).  1 / 1
+ * of the input channels for all rows and summed their accumulators (F16M8 at small and mid batches).  1 / 1
  * for ordinary tiles, 0 / 0 before the first pass. */
 int nsg_get_last_split(nsg_evaluator* ev, int* row_split, int* k_split);
 /* Arithmetic the most recent forward pass ran its trunk in (NSG_PRECISION_*; -1 before
- * the first pass).  An F16M8 evaluator runs its smallest batches (up to CUs/4 boards at 256
- * channels) as F16X3. */
+ * the first pass).  An F16M8 evaluator runs small batches for which it has no F16M8 tile plan
+ * (channel counts other than 256) as F16X3. */
 int nsg_get_last_trunk_precision(nsg_evaluator* ev, int* precision);
 
 /* CPU stand-in executors of the reference (src/infer/zero.cc, nothing.cc,

@@ -247,8 +247,7 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1>
 __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
     using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? (KS > 1 ? 8 : 4) : 2)>;
-    static_assert(KS == 1 || (PREC == kF16m8 && MODE == kConv && SIZE == 1 && MS == 1 && NWAVES % KS == 0 &&
-                              G::kMF % KS == 0),
+    static_assert(KS == 1 || (PREC == kF16m8 && MODE == kConv && SIZE == 1 && MS == 1 && NWAVES % KS == 0),
                   "K split: kF16m8 one-board conv tiles");
     const bool hasRes = (RES == 1) || (RES == 2 && A.res != nullptr);
     NSG_STAMP(0);
@@ -545,7 +544,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         if constexpr (KS > 1) {
             // Sum the K parts: every wave publishes its accumulators, then keeps the row fragments
             // kpart*kMFe .. +kMFe-1 of its channel group, added up in part order (deterministic).
-            constexpr int kMFe = kMFw / KS;
+            // (KS = 4 on six fragments: two per wave, the last wave's two past the tile -- it adds up
+            // whatever lies there and its stores are masked like any padded row)
+            constexpr int kMFe = (kMFw + KS - 1) / KS;
             u32x4* xb = reinterpret_cast<u32x4*>(smem);
 #pragma unroll
             for (int f = 0; f < kMFw; ++f)
@@ -874,7 +875,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 
     if constexpr (MODE == kConv && NFRAG == 4) {
         // (K split: after the exchange a wave owns kMFe of the row fragments, from fBaseE on)
-        constexpr int kMFe = kMFw / KS;
+        constexpr int kMFe = (kMFw + KS - 1) / KS;
         const int fBaseE = fBase + ((KS > 1) ? (wave % KS) * kMFe : 0);
         // ---- convolution epilogue, staged through LDS so that every global access is
         // a full-line, lane-linear 16-byte access.  In the MFMA result layout a lane

@@ -10,6 +10,12 @@ hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStrea
     if (p.nfrag != 4) return hipErrorInvalidValue;
     // mid batches: one board per workgroup, two wave groups on three row fragments each
     // ... or, where all the board's chunk tiles fit in LDS at once, two K halves on all six row fragments
+    if (p.ksplit == 4 && p.nb == 1 && p.nwaves == 4) {
+        // small batches: four K quarters on one 64-channel group (four workgroups per board); a layer with
+        // fewer than four chunk pairs (the stem) runs the two-halves kernel
+        if ((a.kdim / 32) % 8 == 0) return launchOne<kF16m8, kConv, 1, 4, 4, 1, 4>(a, gx, s);
+        return launchOne<kF16m8, kConv, 1, 4, 4, 1, 2>(a, gx, s);
+    }
     if (p.ksplit == 2 && p.nb == 1 && p.nwaves == 4) return launchOne<kF16m8, kConv, 1, 4, 4, 1, 2>(a, gx, s);
     if (p.msplit == 2 && p.nb == 1 && p.nwaves == 4) return launchOne<kF16m8, kConv, 1, 4, 4, 2>(a, gx, s);
 #define NSG_CASE(NB_, NW_) \

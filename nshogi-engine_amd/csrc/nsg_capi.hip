@@ -395,6 +395,13 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         ev->tuning.msplit != 1) {
         const long cus = ev->prop.multiProcessorCount;
         const long wgM8 = (long)B * (ev->F / 128);
+        const int k4max = [] { const char* e = getenv("NSG_KSPLIT4_MAX_BATCH"); return e ? atoi(e) : -1; }();
+        if (ev->F == 256 && ev->cpad == 128 && ev->tuning.msplit != 2 &&
+            (k4max >= 0 ? B <= k4max : (long)B * 4 <= cus)) {
+            // small batches: four workgroups per board, each one 64-channel group whose four waves take one chunk
+            // pair apiece (K split by four, whole board resident in LDS)
+            plan.nb = 1; plan.nfrag = 4; plan.nwaves = 4; plan.msplit = 1; plan.ksplit = 4;
+        } else
         if (wgM8 <= cus && wgM8 * 2 > cus) { // (measured: 1.17-1.29 ms for every B in 65..128; kF16x3 plans 1.26-1.54 ms)
             plan.nb = 1; plan.nfrag = 4; plan.nwaves = 4; plan.msplit = 2;
             // K split instead of the row split where the whole board fits in LDS (<= 256 channels) and both

@@ -135,9 +135,10 @@ def test_f16m8_vs_oracle(nsg, oracle, monkeypatch, blocks, channels, batch):
 
 
 def test_f16m8_small_batches_run_as_f16x3(nsg, oracle):
-    """An f16m8 evaluator keeps the trunk in both forms: batches too small for full tiles
-    take the f16x3 small-tile kernels (f32-equivalent), larger ones the MX path."""
-    ev, blob = make(nsg, 2, 256, 300, precision="f16m8", seed=44)
+    """An f16m8 evaluator keeps the trunk in both forms: where no f16m8 plan fits a small batch
+    (here 192 channels: three chunk pairs do not split over the waves) it takes the f16x3
+    small-tile kernels (f32-equivalent), larger batches the MX path."""
+    ev, blob = make(nsg, 2, 192, 300, precision="f16m8", seed=44)
     net = oracle.net(blob)
     bb = nsg.synth.random_batch(300, 86, seed=12)
     p, v, d = ev.compute_blocking(bb[:16])
@@ -175,37 +176,42 @@ def test_load_device_blob_matches_load_memory(nsg):
         hip.hipFree(dev)
 
 
-@pytest.mark.parametrize("channels,batch", [(256, 70), (256, 101), (256, 128), (128, 200)])
-def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch):
-    """Mid batches (one workgroup per board and 128 output channels fills more than half the CUs):
-    the two waves of a channel group each run half of the input-channel chunk pairs over all six
-    row fragments, with the whole board resident in eight LDS image buffers, and add their
-    accumulators through LDS.  Against the oracle, against the f16x3 evaluator on every board,
-    and against the row-split plan of the same arithmetic (the f32 sums differ in their last bit by
-    summation order; the fp8 rounding of the low term then turns some of those into differences of the
-    size of the format's own error, ~6e-5 here)."""
+@pytest.mark.parametrize("channels,batch,ksplit", [(256, 70, 2), (256, 101, 2), (256, 128, 2), (128, 200, 2),
+                                                   (256, 1, 4), (256, 7, 4), (256, 40, 4), (256, 64, 4)])
+def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch, ksplit):
+    """One-board kF16m8 tiles split by K, the whole board resident in eight LDS image buffers.
+    Mid batches (one workgroup per board and 128 output channels fills more than half the CUs): the
+    two waves of a channel group each run half of the input-channel chunk pairs over all six row
+    fragments.  Small batches (at most CUs/4 boards, 256 channels): four workgroups per board, one
+    64-channel group each, its four waves one chunk pair apiece (the stem, with two pairs, runs the
+    two-halves kernel).  The waves add their accumulators through LDS.  Against the oracle, against
+    the f16x3 evaluator on every board, and -- two halves -- against the row-split plan of the same
+    arithmetic (the f32 sums differ in their last bit by summation order; the fp8 rounding of the low
+    term then turns some of those into differences of the size of the format's own error, ~6e-5 here)."""
     probe = nsg.Evaluator(0, 1, 86)
     cus = probe.info()["compute_units"]
     del probe
     wg = batch * (channels // 128)
-    if not (wg <= cus < 2 * wg):
+    if (ksplit == 2 and not (wg <= cus < 2 * wg)) or (ksplit == 4 and batch * 4 > cus):
         pytest.skip("batch range of this plan depends on the CU count")
-    ev, blob = make(nsg, 3, channels, batch, precision="f16m8", seed=63)
+    bmax = max(batch, 2)
+    ev, blob = make(nsg, 3, channels, bmax, precision="f16m8", seed=63)
     bb = nsg.synth.random_batch(batch, 86, seed=64, garbage=True)
     p, v, d = ev.compute_blocking(bb)
     plan = ev.last_plan()
-    assert plan["trunk_precision"] == "f16m8" and plan["boards_per_group"] == 1 and plan["k_split"] == 2 and plan["row_split"] == 1
-    idx = [0, batch // 2, batch - 1]
+    assert plan["trunk_precision"] == "f16m8" and plan["boards_per_group"] == 1 and plan["k_split"] == ksplit and plan["row_split"] == 1
+    idx = sorted({0, batch // 2, batch - 1})
     check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
-    x3, _ = make(nsg, 3, channels, batch, precision="f16x3", seed=63)
+    x3, _ = make(nsg, 3, channels, bmax, precision="f16x3", seed=63)
     p3, v3, d3 = x3.compute_blocking(bb)
     assert float(np.abs(p - p3).max()) < TOL and float(np.abs(v - v3).max()) < TOL and float(np.abs(d - d3).max()) < TOL
-    monkeypatch.setenv("NSG_CONV_MSPLIT", "2")
-    rows, _ = make(nsg, 3, channels, batch, precision="f16m8", seed=63)
-    pr, vr, dr = rows.compute_blocking(bb)
-    plan = rows.last_plan()
-    assert plan["row_split"] == 2 and plan["k_split"] == 1
-    assert float(np.abs(p - pr).max()) < 3e-4 and float(np.abs(v - vr).max()) < 1e-4 and float(np.abs(d - dr).max()) < 1e-4
+    if ksplit == 2:
+        monkeypatch.setenv("NSG_CONV_MSPLIT", "2")
+        rows, _ = make(nsg, 3, channels, bmax, precision="f16m8", seed=63)
+        pr, vr, dr = rows.compute_blocking(bb)
+        plan = rows.last_plan()
+        assert plan["row_split"] == 2 and plan["k_split"] == 1
+        assert float(np.abs(p - pr).max()) < 3e-4 and float(np.abs(v - vr).max()) < 1e-4 and float(np.abs(d - dr).max()) < 1e-4
     # a forward is deterministic: the same bits again, also at another slot of the batch
     p2, v2, d2 = ev.compute_blocking(bb[::-1].copy())
     np.testing.assert_array_equal(p2[::-1], p)
