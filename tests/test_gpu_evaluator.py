@@ -136,8 +136,8 @@ def test_f16m8_vs_oracle(nsg, oracle, monkeypatch, blocks, channels, batch):
 
 def test_f16m8_small_batches_run_as_f16x3(nsg, oracle):
     """An f16m8 evaluator keeps the trunk in both forms: where no f16m8 plan fits a small batch
-    (here 192 channels: three chunk pairs do not split over the waves) it takes the f16x3
-    small-tile kernels (f32-equivalent), larger batches the MX path."""
+    (here 192 channels: three chunk pairs; a three-way K split measured 3-5 % slower than these) it
+    takes the f16x3 small-tile kernels (f32-equivalent), larger batches the MX path."""
     ev, blob = make(nsg, 2, 192, 300, precision="f16m8", seed=44)
     net = oracle.net(blob)
     bb = nsg.synth.random_batch(300, 86, seed=12)
@@ -192,7 +192,7 @@ def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch, ksplit):
     cus = probe.info()["compute_units"]
     del probe
     wg = batch * (channels // 128)
-    if (ksplit == 2 and not (wg <= cus < 2 * wg)) or (ksplit == 4 and batch * 4 > cus):
+    if (ksplit == 2 and not (wg <= cus < 2 * wg)) or (ksplit in (3, 4) and batch * ksplit > cus):
         pytest.skip("batch range of this plan depends on the CU count")
     bmax = max(batch, 2)
     ev, blob = make(nsg, 3, channels, bmax, precision="f16m8", seed=63)
