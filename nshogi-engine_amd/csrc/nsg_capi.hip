@@ -395,7 +395,8 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         ev->tuning.msplit != 1) {
         const long cus = ev->prop.multiProcessorCount;
         const long wgM8 = (long)B * (ev->F / 128);
-        const int k4max = [] { const char* e = getenv("NSG_KSPLIT4_MAX_BATCH"); return e ? atoi(e) : -1; }();
+        // (NSG_KSPLIT4_MAX_BATCH: experiment knob, read once -- largest batch that takes the four-way K split)
+        static const int k4max = [] { const char* e = getenv("NSG_KSPLIT4_MAX_BATCH"); return e ? atoi(e) : -1; }();
         if (ev->F == 256 && ev->cpad == 128 && ev->tuning.msplit != 2 &&
             (k4max >= 0 ? B <= k4max : (long)B * 4 <= cus)) {
             // small batches: four workgroups per board, each one 64-channel group whose four waves take one chunk
