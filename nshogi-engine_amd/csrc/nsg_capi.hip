@@ -1003,7 +1003,8 @@ int nsg_get_info(nsg_evaluator* ev, nsg_info* info) {
     // stem + trunk + 1x1 policy (value/draw heads excluded)
     info->flops_per_position = 2.0 * 81 * 9 * C * F + N * 2 * (2.0 * 81 * 9 * F * F) + 2.0 * 81 * 27 * F;
     info->trunk_conv_flops_per_position = 2.0 * 81 * 9 * F * F;
-    snprintf(info->device_name, sizeof(info->device_name), "%s", ev->prop.name);
+    // (boxes without the amdgpu.ids table report an empty marketing name: fall back to the ISA name)
+    snprintf(info->device_name, sizeof(info->device_name), "%s", ev->prop.name[0] ? ev->prop.name : ev->prop.gcnArchName);
     return NSG_OK;
 }
 
