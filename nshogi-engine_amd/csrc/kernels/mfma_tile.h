@@ -417,12 +417,14 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     stAll[c][k] = u32x4{0u, 0u, 0u, 0u};
                     if (c < nkc) stAll[c][k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)c * 128);
                 }
+            NSG_STAMP(4); // (diagnostic builds) setup done, every tile load issued
             if (zeroLds) {
                 for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
                     reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
                 }
             }
             __syncthreads();
+            NSG_STAMP(5); // image cleared; what follows waits for the tile loads
 #pragma unroll
             for (int c = 0; c < kChunks; ++c)
 #pragma unroll

@@ -27,6 +27,9 @@ for l in range(2 * blocks):
     d = {"layer": l, "wgs": int(ok.sum()),
          "start_spread": float(s[:, 0].max() - t0),
          "prologue": float(np.median(s[:, 1] - s[:, 0])),
+         "prologue_setup_and_issue": float(np.median(s[:, 4] - s[:, 0])) if s[:, 4].any() else None,  # K-split kernels only
+         "prologue_clear_lds": float(np.median(s[:, 5] - s[:, 4])) if s[:, 4].any() else None,
+         "prologue_wait_tiles_and_stage": float(np.median(s[:, 1] - s[:, 5])) if s[:, 4].any() else None,
          "mainloop": float(np.median(s[:, 2] - s[:, 1])),
          "epilogue": float(np.median(s[:, 3] - s[:, 2])),
          "epilogue_max": float((s[:, 3] - s[:, 2]).max()),
@@ -35,5 +38,5 @@ for l in range(2 * blocks):
          "mhz": float(np.median((s[:, 3] - s[:, 0]) / np.maximum(s[:, 6] - s[:, 7], 1)) * 100.0)}
     res.append(d)
 print(json.dumps(res[2:6], indent=0))
-agg = {k: float(np.mean([r[k] for r in res[2:]])) for k in res[0] if k not in ("layer", "wgs")}
+agg = {k: float(np.mean([r[k] for r in res[2:]])) for k in res[0] if k not in ("layer", "wgs") and res[2][k] is not None}
 print("mean over layers:", json.dumps(agg))
