@@ -157,9 +157,11 @@ def main():
                     choices=["fp32", "fp16", "bf16", "f16x3", "f16m8"])
     ap.add_argument("--selfplay-seconds", type=float, default=30.0,
                     help="length of the self-play leg (metric #2, games/sec); 0 disables it")
-    # BASELINE configs[3]: 256 concurrent games per GPU = 2 threads x 2 groups x 64 games
-    ap.add_argument("--selfplay-threads", type=int, default=2)
-    ap.add_argument("--selfplay-games-per-group", type=int, default=64)
+    # BASELINE configs[3]: 256 concurrent games per GPU = 1 thread x 2 groups x 128 games (one search thread keeps up
+    # with the evaluator at this size and its leaf batches are twice as large: 110-113k evals/s, 536-550 moves/s
+    # against 83-87k / 468-484 for 2 x 2 x 64 -- profiles/r01/h_selfplay_shape_256_games.txt)
+    ap.add_argument("--selfplay-threads", type=int, default=1)
+    ap.add_argument("--selfplay-games-per-group", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     args = ap.parse_args()
