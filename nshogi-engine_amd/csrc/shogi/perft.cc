@@ -3,8 +3,14 @@
 //   movecount <sfen>                number of legal moves
 //   crosscheck <games> <seed>       random playouts: fast generator == slow generator,
 //                                   do/undo restores the hash, sfen round-trips
+//   features <games> <seed> <maxply> <blackdraw> [stop]
+//                                   random playouts (Moves[Mt() % size], the shape of
+//                                   src/test/test_extractbit.cc:66-91); one line per position:
+//                                   sfen TAB hex(86 x 16-byte feature bitboards) TAB usi:index ...
+//   featuresat <maxply> <blackdraw> <sfen>   the same line for one given position
 #include "shogi.h"
 #include "dfpn.h"
+#include "features.h"
 
 #include <functional>
 
@@ -231,6 +237,55 @@ int main(int Argc, char** Argv) {
         const double Ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - T0).count();
         std::cout << "positions " << Pos.size() << " mates " << Found << " budget_exhausted " << Exhausted << " nodes/solve "
                   << (double)Nodes / Pos.size() << " ns/node " << Ns / Nodes << " us/solve " << Ns / 1000.0 / Pos.size() << std::endl;
+        return 0;
+    }
+    if (Cmd == "features" || Cmd == "featuresat") {
+        // Dumps what the self-play path feeds the evaluator (FeatureType::constructAt,
+        // selfplay/evaluationworker.cc:87-92) and the policy index of every legal move
+        // (ml::getMoveIndex, selfplay/frame.cc:102-105); the checks live in tests/shogi_ref.py,
+        // which rebuilds both from the SFEN text alone.
+        auto Dump = [](const State& S, const StateConfig& Config) {
+            FeaturePlane Planes[NumFeaturePlanes];
+            buildFeatures(S, Config, Planes);
+            std::string Hex;
+            static const char* Digits = "0123456789abcdef";
+            const unsigned char* Bytes = reinterpret_cast<const unsigned char*>(Planes);
+            for (size_t I = 0; I < sizeof(Planes); ++I) {
+                Hex += Digits[Bytes[I] >> 4];
+                Hex += Digits[Bytes[I] & 15];
+            }
+            std::cout << S.toSfen() << "\t" << Hex << "\t";
+            MoveList L;
+            S.generateLegalMoves(L);
+            for (int I = 0; I < L.size(); ++I)
+                std::cout << (I ? " " : "") << moveToUsi(L[I]) << ":" << moveIndex(S.sideToMove(), L[I]);
+            std::cout << "\n";
+        };
+        StateConfig Config;
+        if (Cmd == "featuresat") {
+            Config.MaxPly = (uint16_t)std::atoi(Argv[2]);
+            Config.BlackDrawValue = (float)std::atof(Argv[3]);
+            Config.WhiteDrawValue = 1.0f - Config.BlackDrawValue;
+            Dump(State::fromSfen(joinArgs(Argc, Argv, 4)), Config);
+            return 0;
+        }
+        const int Games = std::atoi(Argv[2]);
+        std::mt19937_64 Rng((uint64_t)std::atoll(Argv[3]));
+        Config.MaxPly = (uint16_t)std::atoi(Argv[4]);
+        Config.BlackDrawValue = (float)std::atof(Argv[5]);
+        Config.WhiteDrawValue = 1.0f - Config.BlackDrawValue;
+        const int Stop = Argc > 6 ? std::atoi(Argv[6]) : (int)Config.MaxPly;
+        for (int G = 0; G < Games; ++G) {
+            State S;
+            Dump(S, Config);
+            for (int Ply = 0; Ply < Stop; ++Ply) {
+                MoveList L;
+                S.generateLegalMoves(L);
+                if (L.size() == 0) break;
+                S.doMove(L[(int)(Rng() % (uint64_t)L.size())]);
+                Dump(S, Config);
+            }
+        }
         return 0;
     }
     if (Cmd == "moves") {

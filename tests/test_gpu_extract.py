@@ -47,6 +47,36 @@ def test_reference_test_shape(nsg, oracle):
                                           oracle.extract_bits(bb, cf).view(np.uint32))
 
 
+def test_walk_a_random_game_like_the_reference_test(nsg, golden_dir):
+    """src/test/test_extractbit.cc:26-91 restated on real positions: one random game from the
+    initial position (mt19937_64(20240203), the committed fixture), and at EVERY ply
+    nsg_extract_bits at batch 1 in both layouts; all C*81 values compared with planes written
+    from the board (tests/shogi_ref.py reads the SFEN), not from the bitboards."""
+    import os
+    import shogi_ref
+    g = np.load(os.path.join(golden_dir, "game_20240203.npz"))
+    assert len(g["sfens"]) > 200
+    for sfen, bb in zip(g["sfens"], g["bitboards"]):
+        want = shogi_ref.expected_planes(str(sfen), 1024, 0.5)  # MaxPly 1024 (test_extractbit.cc:31-35)
+        got_cf = run_extract(nsg, bb[None], True)[0]
+        got_cl = run_extract(nsg, bb[None], False)[0]
+        np.testing.assert_array_equal(got_cf, want, err_msg=str(sfen))
+        np.testing.assert_array_equal(got_cl, want.T, err_msg=str(sfen))
+
+
+def test_walk_fresh_random_games_whole_batch(nsg):
+    """Further games played now by the build's rules core (perft features), expanded as one
+    batch per game in both layouts."""
+    import test_features
+    import shogi_ref
+    for seed in (1, 2):
+        rows = test_features.dump(1, seed, 1024, 0.5, 1024)
+        bb = np.stack([r[1] for r in rows])
+        want = np.stack([shogi_ref.expected_planes(r[0]) for r in rows])
+        np.testing.assert_array_equal(run_extract(nsg, bb, True), want)
+        np.testing.assert_array_equal(run_extract(nsg, bb, False), np.swapaxes(want, 1, 2))
+
+
 def test_full_size_properties(nsg):
     """B = 1024 (config 5): rotate-involution and popcount properties that do
     not need the oracle at full size."""
