@@ -76,11 +76,23 @@ int nsg_destroy(nsg_evaluator* ev);
 int nsg_set_precision(nsg_evaluator* ev, int precision);
 
 /* Replaces infer::TensorRT::load(const std::string& Path, bool) --
- * src/infer/trt.h:47, src/infer/trt.cc:109-232.  `path` names an NSGW v1
- * weight file (DESIGN.md "Weight file"); BN is folded and the weights are
- * re-laid into MFMA fragment order on upload.  The policy width is checked
- * against NSG_MOVE_INDEX_MAX as trt.cc:193-210 does. */
+ * src/infer/trt.h:47, src/infer/trt.cc:109-232.  `path` names either the
+ * ONNX model file the engine passes (trt.cc:121-131, default
+ * ./res/model.onnx, src/context.h:93) or an NSGW v1 weight file (DESIGN.md
+ * "Weight file"); the two are told apart by their first bytes.  An ONNX model
+ * must be of the topology family this library runs (csrc/onnx_reader.h) and
+ * obey the reference's tensor contract (input "input", outputs "policy",
+ * "value", "draw", trt.cc:144-150,193-227); anything else fails with
+ * NSG_E_FORMAT and a message naming the node (the reference's parser failure,
+ * trt.cc:127-131).  BN is folded and the weights are re-laid into MFMA
+ * fragment order on upload.  The policy width is checked against
+ * NSG_MOVE_INDEX_MAX as trt.cc:193-210 does. */
 int nsg_load(nsg_evaluator* ev, const char* path);
+/* The ONNX -> NSGW v1 conversion nsg_load applies, on host memory and with no
+ * device: writes *nsgw_size and, if dst != NULL, the blob (capacity bytes
+ * available).  Call with dst = NULL first to size the buffer. */
+int nsg_convert_onnx(const void* onnx, size_t size, void* dst, size_t capacity,
+                     size_t* nsgw_size);
 /* Same, from a host blob / from a device-resident blob (e.g. the buffer an
  * RCCL broadcast just filled). */
 int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size);

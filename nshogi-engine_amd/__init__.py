@@ -15,6 +15,7 @@ from .capi import (  # noqa: F401
     Evaluator,
     CpuExecutor,
     extract_bits,
+    convert_onnx,
     load_library,
     library_path,
     PRECISION_FP32,
@@ -27,7 +28,7 @@ from .capi import (  # noqa: F401
 from . import weights, synth, dist, onnx_io, teacher  # noqa: F401
 
 __all__ = [
-    "NsgError", "Evaluator", "CpuExecutor", "extract_bits", "load_library",
+    "NsgError", "Evaluator", "CpuExecutor", "extract_bits", "convert_onnx", "load_library",
     "library_path", "weights", "synth", "dist", "onnx_io", "teacher", "PRECISION_FP32", "PRECISION_FP16",
     "PRECISION_BF16", "PRECISION_F16X3", "MOVE_INDEX_MAX", "NUM_SQUARES",
 ]

@@ -72,6 +72,7 @@ def load_library():
     lib.nsg_destroy.argtypes = [vp]
     lib.nsg_set_precision.argtypes = [vp, i]
     lib.nsg_load.argtypes = [vp, ctypes.c_char_p]
+    lib.nsg_convert_onnx.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
     lib.nsg_load_memory.argtypes = [vp, vp, sz]
     lib.nsg_load_device_blob.argtypes = [vp, vp, sz]
     for name in ("nsg_compute_nonblocking", "nsg_compute_blocking"):
@@ -303,6 +304,17 @@ class CpuExecutor:
             self.close()
         except Exception:
             pass
+
+
+def convert_onnx(data):
+    """nsg_convert_onnx: the ONNX -> NSGW v1 conversion nsg_load applies (host only, no device)."""
+    lib = load_library()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    need = ctypes.c_size_t()
+    _check(lib.nsg_convert_onnx(_ptr(buf), buf.size, None, 0, ctypes.byref(need)))
+    out = np.empty(need.value, dtype=np.uint8)
+    _check(lib.nsg_convert_onnx(_ptr(buf), buf.size, _ptr(out), out.size, ctypes.byref(need)))
+    return out.tobytes()
 
 
 def extract_bits(dst_ptr, src_ptr, batch_size, num_channels, channels_first=True, stream=0):

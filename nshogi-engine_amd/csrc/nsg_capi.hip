@@ -8,6 +8,7 @@
 // every compute entry fails with NSG_E_HIP when no device is usable.
 #include "../../include/nsg.h"
 #include "kernels/kernels.h"
+#include "onnx_reader.h"
 
 #include <hip/hip_runtime.h>
 
@@ -608,8 +609,29 @@ int nsg_set_precision(nsg_evaluator* ev, int precision) {
     return NSG_OK;
 }
 
+int nsg_convert_onnx(const void* onnx, size_t size, void* dst, size_t capacity, size_t* nsgw_size) {
+    if (!onnx || !nsgw_size) return fail(NSG_E_INVALID, "null argument");
+    std::vector<unsigned char> blob;
+    std::string err;
+    if (!nsg::onnx::convertToNsgw(onnx, size, &blob, &err)) return fail(NSG_E_FORMAT, "%s", err.c_str());
+    *nsgw_size = blob.size();
+    if (dst) {
+        if (capacity < blob.size()) return fail(NSG_E_INVALID, "destination holds %zu bytes, %zu needed", capacity, blob.size());
+        memcpy(dst, blob.data(), blob.size());
+    }
+    return NSG_OK;
+}
+
 int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
     if (!ev || !blob) return fail(NSG_E_INVALID, "null argument");
+    if (!nsg::onnx::isNsgw(blob, size)) { // what the engine passes: an ONNX model (trt.cc:121-131)
+        std::vector<unsigned char> converted;
+        std::string err;
+        if (!nsg::onnx::convertToNsgw(blob, size, &converted, &err))
+            return fail(NSG_E_FORMAT, "Failed to parse the model: neither an NSGW v1 weight file nor an ONNX model of the "
+                                      "supported topology (%s)", err.c_str());
+        return nsg_load_memory(ev, converted.data(), converted.size());
+    }
     int rc = bind(ev);
     if (rc) return rc;
     NetView nv;

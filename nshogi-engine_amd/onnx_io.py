@@ -13,9 +13,12 @@ The reference loads whatever ONNX file it is given through TensorRT's parser
     1x1 value conv + BN + ReLU + two dense layers, value = (tanh+1)/2 or sigmoid,
     draw = sigmoid.  Anything else is refused with a message naming the node.
 
-The protobuf wire format is hand-coded from the public onnx.proto3 field numbers; the
-files have been round-tripped through this reader only (no onnxruntime here to check them
-against): treat interoperability as unverified until a run with the real tools.
+The protobuf wire format is hand-coded from the public onnx.proto3 field numbers.  The READER
+is pinned against models serialised by PyTorch's own ONNX exporter (tests/golden/net_torch_*.onnx,
+made by tests/golden/make_onnx_golden.py); the product-side reader is the C++ one inside
+libnsg.so (csrc/onnx_reader.cc, used by nsg_load) and this module is its independent cross-check
+in the tests.  The WRITER has only been read back by these two readers (no onnxruntime / TensorRT
+here): unverified against the real consumers.
 """
 import struct
 
@@ -335,6 +338,11 @@ def read_onnx(data):
             for vf, _, vv in _parse(v):
                 if vf == 1:
                     (ins if f == 11 else outs).append(bytes(vv).decode())
+    for nd in nodes:  # Constant nodes are initializers in all but name (torch emits them for scalar literals)
+        if nd.op == "Constant" and len(nd.outputs) == 1:
+            v = nd.attrs.get("value", nd.attrs.get("value_float"))
+            if v is not None:
+                inits[nd.outputs[0]] = np.asarray(v, np.float32) if not isinstance(v, np.ndarray) else v
     return nodes, inits, [i for i in ins if i not in inits], outs
 
 
@@ -479,8 +487,17 @@ def import_onnx(data, bn_eps_default=1e-5):
         if nd2.op == "Tanh":  # (tanh(o) + 1) / 2
             a = only(nd2.outputs[0], "tanh shift")
             m2 = only(a.outputs[0], "tanh scale")
-            if a.op != "Add" or m2.op != "Mul":
-                fail(a, "expected (tanh + 1) * 0.5")
+
+            def scalar(node, t):
+                other = [i for i in node.inputs if i != t]
+                c = inits.get(other[0]) if len(other) == 1 else None
+                if c is None or c.size != 1 or (node.op == "Div" and node.inputs[0] != t):
+                    fail(node, "expected a scalar float constant operand")
+                return float(np.asarray(c).reshape(-1)[0])
+            if a.op != "Add" or scalar(a, nd2.outputs[0]) != 1.0:
+                fail(a, "expected tanh + 1")
+            if not ((m2.op == "Mul" and scalar(m2, a.outputs[0]) == 0.5) or (m2.op == "Div" and scalar(m2, a.outputs[0]) == 2.0)):
+                fail(m2, "expected (tanh + 1) * 0.5 or (tanh + 1) / 2")
             name = m2.outputs[0]
         elif nd2.op == "Sigmoid":
             name = nd2.outputs[0]

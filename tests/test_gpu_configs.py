@@ -1,0 +1,117 @@
+"""BASELINE.json's configurations at their full sizes on the HIP path (one GPU):
+  configs[1]  batch 64, 10x192, default arithmetic (f16m8 evaluator)
+  configs[3]  self-play, 256 concurrent games per GPU, 800 playouts/move, 20x256
+  configs[4]  40x384, batch 1024, bf16 (and the 1e-3 path, f16m8)
+A sample of boards goes through the CPU oracle (6 s per board at 40x384); everything else is
+checked by size-independent properties: bit-exact independence from slot and batch composition,
+value/draw ranges, finiteness, run-to-run determinism."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SELFPLAY = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "selfplay", "selfplay")
+TOL = 1e-3  # north_star
+
+
+def make(nsg, blocks, channels, batch_max, precision, seed=0, bn="identity"):
+    blob = nsg.weights.to_blob(nsg.weights.make_random(blocks, channels, seed=seed, bn=bn))
+    ev = nsg.Evaluator(0, batch_max, 86, precision=precision)
+    ev.load_memory(blob)
+    return ev, blob
+
+
+def err(a, b):
+    return max(float(np.abs(x - y).max()) for x, y in zip(a, b))
+
+
+def test_config1_10x192_batch64_default_precision(nsg, oracle):
+    """configs[1] in bench.py's default arithmetic.  At 192 channels and 64 boards an f16m8
+    evaluator runs its f16x3 small tiles (f32-equivalent): every 8th board against the oracle."""
+    ev, blob = make(nsg, 10, 192, 64, "f16m8", seed=1)
+    bb = nsg.synth.random_batch(64, 86, seed=2)
+    p, v, d = ev.compute_blocking(bb)
+    assert ev.last_plan()["trunk_precision"] in ("f16x3", "f16m8")
+    idx = list(range(0, 64, 8)) + [63]
+    assert err((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx])) < TOL
+    perm = np.random.default_rng(0).permutation(64)
+    p2, v2, d2 = ev.compute_blocking(bb[perm])
+    np.testing.assert_array_equal(p2, p[perm])
+    np.testing.assert_array_equal(v2, v[perm])
+    assert np.isfinite(p).all() and ((v >= 0) & (v <= 1)).all() and ((d >= 0) & (d <= 1)).all()
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16", 1.5e-1), ("f16m8", TOL)])
+def test_config4_40x384_batch1024(nsg, oracle, precision, tol):
+    """configs[4]: 40-block x 384-channel net at batch 1024.  bf16 is the configuration's own
+    arithmetic (8-bit mantissa operands, f32 accumulate; measured 9.6e-2 on the logits of this net,
+    tolerance 1.5e-1 as for every bf16 test of this suite); f16m8 is held to the north_star's 1e-3."""
+    ev, blob = make(nsg, 40, 384, 1024, precision, seed=5)
+    bb = nsg.synth.random_batch(1024, 86, seed=6)
+    p, v, d = ev.compute_blocking(bb)
+    assert ev.last_plan()["trunk_precision"] == precision
+    assert np.isfinite(p).all() and ((v >= 0) & (v <= 1)).all() and ((d >= 0) & (d <= 1)).all()
+    idx = [0, 517, 1023]
+    ref = oracle.net(blob).evaluate(bb[idx])
+    scale = max(1.0, float(np.abs(ref[0]).max())) if precision == "bf16" else 1.0
+    assert float(np.abs(p[idx] - ref[0]).max()) <= tol * scale
+    assert float(np.abs(v[idx] - ref[1]).max()) <= tol and float(np.abs(d[idx] - ref[2]).max()) <= tol
+    # slot / batch-composition independence, bit for bit, at the full size
+    perm = np.random.default_rng(1).permutation(1024)
+    p2, v2, d2 = ev.compute_blocking(bb[perm])
+    np.testing.assert_array_equal(p2, p[perm])
+    np.testing.assert_array_equal(v2, v[perm])
+    np.testing.assert_array_equal(d2, d[perm])
+    # the reference benchmark's input: one position in every slot (bench/batchsize.cc:52-59)
+    rep = np.repeat(bb[3:4], 1024, axis=0)
+    pr, vr, dr = ev.compute_blocking(rep)
+    assert (pr == pr[0]).all() and (vr == vr[0]).all() and (dr == dr[0]).all()
+    np.testing.assert_array_equal(pr[0], p[3])
+
+
+def run_selfplay(*args, timeout=600):
+    r = subprocess.run([SELFPLAY] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(r.stdout.strip().split("\n")[-1])
+
+
+def test_config3_selfplay_256_games_800_playouts(nsg, tmp_path):
+    """configs[3] on one GPU: 256 concurrent games (one search thread, two groups of 128 --
+    bench.py's shape), 800 playouts per full search, the 20x256 net in bench.py's arithmetic.
+    Run twice to a fixed number of finished games: the move digest is reproducible bit for bit,
+    batches average near the group size, every finished game is in the teacher file and its
+    records chain move by move from the initial position."""
+    wpath = tmp_path / "net.nsgw"
+    nsg.weights.save(str(wpath), nsg.weights.make_random(20, 256, seed=0, bn="identity"))
+    tpath = tmp_path / "games.nsgt"
+    base = ["--executor", "hip", "--weights", wpath, "--precision", 4, "--threads", 1, "--games-per-group", 128,
+            "--playouts", 800, "--max-games", 6, "--seed", 21]
+    a = run_selfplay(*base, "--teacher", tpath)
+    b = run_selfplay(*base)
+    assert a["concurrent_games"] == 256 and a["playouts_per_move"] == 800
+    assert a["games_finished"] >= 6 and a["digest"] == b["digest"] and a["moves"] == b["moves"]
+    assert a["black"] + a["white"] + a["draw"] == a["games_finished"]
+    assert 100 <= a["avg_batch"] <= 128, a
+    assert a["evals_per_sec"] > 0 and 0 <= a["cache_hit_ratio"] < 1
+    rec = nsg.teacher.load(str(tpath))
+    assert len(rec) == a["teacher_records"] > 0
+    on_board = (rec["board"] != 0).sum(axis=1) + rec["hands"].reshape(len(rec), -1).sum(axis=1)
+    assert np.all(on_board == 40) and np.all(rec["side_to_move"] == rec["ply"] % 2)
+    cuts = [0] + [i for i in range(1, len(rec)) if rec["ply"][i] <= rec["ply"][i - 1]] + [len(rec)]
+    assert len(cuts) - 1 == a["games_finished"]
+    chained = 0
+    for s, e in zip(cuts[:-1], cuts[1:]):
+        g = rec[s:e]
+        for k in range(len(g) - 1):
+            if g["ply"][k + 1] != g["ply"][k] + 1:
+                continue
+            brd, hnd = nsg.teacher.apply_move(g["board"][k], g["hands"][k], int(g["side_to_move"][k]),
+                                              int(g["next_move16"][k]))
+            assert np.array_equal(brd, g["board"][k + 1]) and np.array_equal(hnd, g["hands"][k + 1])
+            chained += 1
+    assert chained > 0

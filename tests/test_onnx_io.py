@@ -72,3 +72,70 @@ def test_refuses_foreign_structures():
         oio.import_onnx(bad)
     with pytest.raises(ValueError):
         oio.import_onnx(b"\x08\x07")
+
+
+# ---- models serialised by PyTorch's own exporter (tests/golden/make_onnx_golden.py) ----------
+
+TORCH_MODELS = [("net_torch_2x64", 2, False), ("net_torch_bn_1x64", 1, True)]
+
+
+@pytest.mark.parametrize("name,blocks,has_bn", TORCH_MODELS)
+def test_torch_exported_model_is_read_and_matches_pytorch(oracle, golden_dir, name, blocks, has_bn):
+    """What the engine passes to load() is an ONNX file (trt.cc:109-131).  A model written by
+    torch.onnx.export: the C++ reader of libnsg.so (nsg_convert_onnx, what nsg_load applies) and
+    the Python importer produce the same NSGW blob bit for bit, and the oracle evaluating that
+    blob on real positions reproduces PyTorch's float64 forward to 1e-5."""
+    data = open(f"{golden_dir}/{name}.onnx", "rb").read()
+    g = np.load(f"{golden_dir}/net_torch.npz")
+    nodes, _, ins, outs = oio.read_onnx(data)
+    assert ins == ["input"] and outs == ["policy", "value", "draw"]
+    assert any(n.op == "BatchNormalization" for n in nodes) == has_bn
+    w = oio.import_onnx(data)
+    m = w["_meta"]
+    assert (m["blocks"], m["channels"], m["in_channels"], m["value_channels"], m["value_hidden"]) == (blocks, 64, 86, 8, 64)
+    blob_py = nsg.weights.to_blob(w)
+    blob_cc = nsg.convert_onnx(data)
+    assert blob_cc == blob_py
+    p, v, d = oracle.net(blob_cc).evaluate(g["bitboards"])
+    assert float(np.abs(p - g[f"{name}_policy"]).max()) < 1e-5
+    assert float(np.abs(v - g[f"{name}_value"]).max()) < 1e-5
+    assert float(np.abs(d - g[f"{name}_draw"]).max()) < 1e-5
+    assert float(np.abs(g[f"{name}_policy"]).max()) > 0.1 and float(g[f"{name}_policy"].std()) > 0.02  # a non-trivial expectation
+
+
+@pytest.mark.parametrize("fold,sig", [(False, False), (True, True)])
+def test_cpp_reader_equals_python_importer_on_this_builds_writer(fold, sig):
+    w = nsg.weights.make_random(2, 64, seed=17, bn="random")
+    data = oio.export_onnx(w, fold_bn=fold, value_sigmoid=sig)
+    assert nsg.convert_onnx(data) == nsg.weights.to_blob(oio.import_onnx(data))
+
+
+def test_cpp_reader_refuses_with_a_message(golden_dir):
+    data = open(f"{golden_dir}/net_torch_2x64.onnx", "rb").read()
+    with pytest.raises(nsg.NsgError, match="policy"):
+        nsg.convert_onnx(data.replace(b"policy", b"polizy"))
+    with pytest.raises(nsg.NsgError):
+        nsg.convert_onnx(data[: len(data) // 2])  # truncated file
+    with pytest.raises(nsg.NsgError, match="no graph"):
+        nsg.convert_onnx(b"\x08\x07")
+    # a structure outside the family: the stem's Relu renamed to another op
+    with pytest.raises(nsg.NsgError, match="Relu"):
+        nsg.convert_onnx(data.replace(b"\x22\x04Relu", b"\x22\x04Selu", 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,blocks,has_bn", TORCH_MODELS)
+def test_nsg_load_accepts_the_onnx_file(golden_dir, name, blocks, has_bn):
+    """nsg_load on the .onnx path itself, as infer::Hip::load(PContext->getWeightPath()) does
+    (mcts/evaluationworker.cc:76-88 -> trt.cc:109): outputs vs PyTorch's float64 forward."""
+    g = np.load(f"{golden_dir}/net_torch.npz")
+    ev = nsg.Evaluator(0, 8, 86, precision="fp32")
+    ev.load(f"{golden_dir}/{name}.onnx")
+    info = ev.info()
+    assert info["blocks"] == blocks and info["channels"] == 64 and info["loaded"] == 1
+    p, v, d = ev.compute_blocking(g["bitboards"])
+    assert float(np.abs(p - g[f"{name}_policy"]).max()) < 1e-4
+    assert float(np.abs(v - g[f"{name}_value"]).max()) < 1e-4 and float(np.abs(d - g[f"{name}_draw"]).max()) < 1e-4
+    with pytest.raises(nsg.NsgError, match="neither an NSGW"):
+        ev2 = nsg.Evaluator(0, 8, 86)
+        ev2.load_memory(b"this is neither format, but long enough to pass the size checks......")
