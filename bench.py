@@ -2,12 +2,16 @@
 """bench.py -- NN evaluations/sec of the MI355X-native evaluator.
 
 Metric (BASELINE.json): "NN evals/sec at batch=512" on the 20-block x 256-channel
-resnet (configs[2]); definition follows the reference's own harness
-/root/reference/src/bench/batchsize.cc:61-79 (evals = BatchSize * Repeat / wall),
-except that -- per the measurement contract -- `value` is the device-resident
-rate: the feature bitboards are already in HBM when the timed region starts and
-the outputs stay in HBM.  The PCIe-inclusive computeBlocking rate (what
-batchsize.cc times) is reported beside it as `host_path_evals_per_sec`.
+resnet (configs[2]).  Input = the reference benchmark's own: the feature stack of the
+initial position in every batch slot (/root/reference/src/bench/batchsize.cc:47-59), built
+by this build's rules core.  Two rates are printed, and the line says which is which:
+  * `value` -- the measurement contract's device-resident rate: the feature bitboards are
+    already in HBM when the timed region starts and the outputs stay in HBM; exactly
+    --steps passes are timed (`sustained_evals_per_sec` is the same loop held for >= 5 s).
+  * `reference_metric.evals_per_sec` -- the reference's own definition,
+    batchsize.cc:61-79: BatchSize * Repeat / wall over back-to-back computeBlocking calls
+    INCLUDING H2D and D2H, held for >= 5 s; `..._distinct_positions` repeats both on B
+    distinct positions of random-playout games.
 
 A "step" = one pass of the hot path over one batch: planes -> resnet -> heads.
 One process per GPU; positions shard across ranks with no data-path collective
@@ -68,38 +72,90 @@ def cpu_baseline(seconds=12.0):
                       f"{os.cpu_count()} host cores ({model})"}
 
 
-def conv_traffic_bytes(args, B):
-    """HBM bytes per trunk-conv launch from the committed rocprofv3 PMC passes of this
-    same workload (profiles/r01/pmc_<precision>_summary.json; FETCH_SIZE doubled for
-    16-byte-per-lane streams per MI355X_MICROARCH.md 'HBM').  None if not profiled."""
+def pmc_summary(args, B):
+    """The committed rocprofv3 PMC passes of this same workload (scripts/pmc.sh ->
+    profiles/rNN/pmc_<precision>_summary.json), newest round first.  These are NOT measured by
+    this run: PMC collection needs its own rocprofv3 passes; the bench line names the file."""
     if args.net != "20x256" or B != 512:
-        return None
-    path = os.path.join(ROOT, "profiles", "r01", f"pmc_{args.precision}_summary.json")
-    try:
-        d = json.load(open(path))
-    except OSError:
-        return None
-    tot, n = 0.0, 0
-    for name, c in d.items():
-        if "tileKernel" in name and ", 0, 2, 4, 4," in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            tot += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-            n += 1
-    return tot / n if n else None
+        return None, None
+    for rnd in ("r02", "r01"):
+        rel = os.path.join("profiles", rnd, f"pmc_{args.precision}_summary.json")
+        try:
+            return json.load(open(os.path.join(ROOT, rel))), rel
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
-def conv_mfma_busy(args, B):
-    """Fraction of the trunk conv's run time its matrix pipes were busy, from the same committed
-    PMC passes: SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES) -- the kernel runs one wave per
-    SIMD and SQ_WAVE_CYCLES counts in units of 4 clocks.  None if not profiled."""
-    if args.net != "20x256" or B != 512:
-        return None
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01", f"pmc_{args.precision}_summary.json")))
-    except OSError:
-        return None
-    v = [c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_WAVE_CYCLES"]) for name, c in d.items()
-         if "tileKernel" in name and ", 0, 2, 4, 4," in name and c.get("SQ_WAVE_CYCLES")]
+def _conv_rows(d):
+    # full-tile trunk conv: tileKernel<PREC, MODE 0 conv, 2 boards, 4 fragments, 4 waves, residual?>
+    return [c for name, c in (d or {}).items() if "tileKernel" in name and ", 0, 2, 4, 4," in name]
+
+
+def conv_traffic_bytes(d):
+    """HBM bytes per trunk-conv launch (FETCH_SIZE doubled for 16-byte-per-lane streams per
+    MI355X_MICROARCH.md 'HBM'; counters are in KiB).  Mean over launches with / without residual."""
+    v = [(2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 for c in _conv_rows(d)
+         if "FETCH_SIZE" in c and "WRITE_SIZE" in c]
     return sum(v) / len(v) if v else None
+
+
+def conv_mfma_busy(d):
+    """Fraction of the trunk conv's run time its matrix pipes were busy:
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES) -- one wave per SIMD, SQ_WAVE_CYCLES counts
+    quad-cycles."""
+    v = [c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_WAVE_CYCLES"]) for c in _conv_rows(d)
+         if c.get("SQ_WAVE_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in c]
+    return sum(v) / len(v) if v else None
+
+
+def extract_roofline(nsg, bb, B):
+    """Second roofline entry: the plane-expansion kernel alone, HBM-bound.
+    Algorithmic bytes per position = 1376 read + 27 864 written.  Timed live with HIP events on
+    the stream the kernel is launched on (torch's current stream, handed to nsg_extract_bits)."""
+    import torch
+    C = 86
+    src = torch.from_numpy(bb.view(np.int64).copy()).cuda()
+    dst = torch.empty(B * C * 81, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for cf, name in ((True, "NCHW"), (False, "NHWC")):
+        for _ in range(5):
+            nsg.extract_bits(dst.data_ptr(), src.data_ptr(), B, C, cf, stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        iters = 200
+        e0.record()
+        for _ in range(iters):
+            nsg.extract_bits(dst.data_ptr(), src.data_ptr(), B, C, cf, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / iters
+    nbytes = B * (1376 + 27864)
+    ms = out["NCHW"]
+    return {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
+            "frac": nbytes / ms / 1e6 / 8000.0, "traffic": None,
+            "kernel": "extractNCHW (nsg_extract_bits, channels first; the reference's K1)",
+            "avg_launch_ms": ms, "launches_timed": 200, "algorithmic_bytes_per_launch": nbytes,
+            "nhwc_avg_launch_ms": out["NHWC"], "nhwc_GB_per_s": nbytes / out["NHWC"] / 1e6,
+            "note": "one launch moves 15 MB at batch 512: launch + first-byte latency, not bandwidth, "
+                    "sets its time (profiles/r02/extract_roofline.json has the batch sweep)"}
+
+
+def held_rate(fn, B, sync, seconds):
+    """evals/s of `fn` called back to back for at least `seconds` (after one untimed call)."""
+    fn()
+    sync()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(8):
+            fn()
+        n += 8
+        if time.perf_counter() - t0 >= seconds:
+            break
+    sync()
+    dt = time.perf_counter() - t0
+    return B * n / dt, n, dt
 
 
 def quick_rate(nsg, local_rank, blob, bb, B, precision, steps=5):
@@ -125,16 +181,20 @@ SELFPLAY_BIN = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "selfplay", "self
 def selfplay_leg(weights_path, gpu, seconds, threads, precision, playouts=800, games_per_group=256):
     """BASELINE metric #2 on this rank's GPU: the self-play driver (csrc/selfplay) with
     the reference's option names/values of config 4 (--num-playouts 800, batch = games per
-    group).  games/sec = finished games / elapsed (saveworker.cc:135-137)."""
+    group).  games/sec = finished games / elapsed (saveworker.cc:135-137).  Never raises: a rank
+    whose driver fails or hangs must still reach the collectives that follow."""
     import subprocess
     prec = {"fp32": 0, "fp16": 1, "bf16": 2, "f16x3": 3, "f16m8": 4}[precision]
-    r = subprocess.run([SELFPLAY_BIN, "--executor", "hip", "--weights", weights_path, "--gpu", str(gpu),
-                        "--threads", str(threads), "--games-per-group", str(games_per_group),
-                        "--playouts", str(playouts), "--seconds", str(seconds), "--seed", "1",
-                        "--precision", str(prec)], capture_output=True, text=True, timeout=seconds * 3 + 300)
-    if r.returncode != 0:
-        return {"error": (r.stderr or r.stdout)[-300:]}
-    return json.loads(r.stdout.strip().split("\n")[-1])
+    try:
+        r = subprocess.run([SELFPLAY_BIN, "--executor", "hip", "--weights", weights_path, "--gpu", str(gpu),
+                            "--threads", str(threads), "--games-per-group", str(games_per_group),
+                            "--playouts", str(playouts), "--seconds", str(seconds), "--seed", "1",
+                            "--precision", str(prec)], capture_output=True, text=True, timeout=seconds * 3 + 300)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        return json.loads(r.stdout.strip().split("\n")[-1])
+    except (subprocess.TimeoutExpired, OSError, ValueError, IndexError) as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def selfplay_cpu_baseline(seconds=8.0):
@@ -155,11 +215,15 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--precision", default=os.environ.get("NSG_BENCH_PRECISION", "f16m8"),
                     choices=["fp32", "fp16", "bf16", "f16x3", "f16m8"])
-    ap.add_argument("--selfplay-seconds", type=float, default=30.0,
+    ap.add_argument("--positions", default="startpos", choices=["startpos", "distinct", "synthetic"],
+                    help="startpos: the initial position in every slot (bench/batchsize.cc:47-59, the default); "
+                         "distinct: B distinct positions of random-playout games; synthetic: seeded random bitboards")
+    ap.add_argument("--sustain-seconds", type=float, default=5.0,
+                    help="length of the sustained (>= 5 s) legs; 0 disables them")
+    ap.add_argument("--selfplay-seconds", type=float, default=60.0,
                     help="length of the self-play leg (metric #2, games/sec); 0 disables it")
-    # BASELINE configs[3]: 256 concurrent games per GPU = 1 thread x 2 groups x 128 games (one search thread keeps up
-    # with the evaluator at this size and its leaf batches are twice as large: 110-113k evals/s, 536-550 moves/s
-    # against 83-87k / 468-484 for 2 x 2 x 64 -- profiles/r01/h_selfplay_shape_256_games.txt)
+    # BASELINE configs[3]: 256 concurrent games per GPU = 1 thread x 2 groups x 128 games
+    # (profiles/r01/h_selfplay_shape_256_games.txt)
     ap.add_argument("--selfplay-threads", type=int, default=1)
     ap.add_argument("--selfplay-games-per-group", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,13 +258,22 @@ def main():
         dev_blob = nsg.dist.broadcast_blob(blob, src=0, device="cuda")
         torch.cuda.synchronize()
         ev.load_device_blob(dev_blob.data_ptr(), dev_blob.numel())
+        if blob is None:  # the self-play leg hands this rank's driver the same bytes
+            blob = dev_blob.cpu().numpy().tobytes()
         del dev_blob
     else:
         ev.load_memory(blob)
     info = ev.info()
 
-    # synthetic positions: B distinct per rank (distinct across ranks too)
-    bb = nsg.synth.random_batch(B, 86, seed=nsg.dist.shard_seed(nsg.synth.SEED, rank), distinct=True)
+    # positions (per rank): the reference benchmark's input, or distinct real / synthetic ones
+    def positions(kind):
+        if kind == "startpos":
+            return nsg.positions.startpos_batch(B)
+        if kind == "distinct":
+            return nsg.positions.game_positions(B, seed=nsg.dist.shard_seed(nsg.synth.SEED, rank))
+        return nsg.synth.random_batch(B, 86, seed=nsg.dist.shard_seed(nsg.synth.SEED, rank), distinct=True)
+
+    bb = positions(args.positions)
     ev.upload_features(bb)
 
     def barrier():
@@ -220,24 +293,42 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = ev.profile_read()
-    ev.profile_enable(False)
 
     if distributed:
         dt = nsg.dist.max_over_ranks(dt, device="cuda")
+
+    # the same loop held for >= 5 s (clocks settled; the kernel is power-limited), HIP-event
+    # timing of the trunk conv over that whole window
+    sustained = None
+    if args.sustain_seconds > 0:
+        ev.profile_read()
+        rate, n, secs = held_rate(lambda: ev.forward_resident(B), B, torch.cuda.synchronize, args.sustain_seconds)
+        sprof = ev.profile_read()
+        if distributed:
+            rate = nsg.dist.sum_over_ranks(rate, device="cuda")
+        sustained = {"evals_per_sec": rate, "steps": n, "seconds": secs,
+                     "conv_avg_launch_ms": sprof["trunk_ms_total"] / max(sprof["trunk_launches"], 1),
+                     "conv_launches_timed": sprof["trunk_launches"]}
+    ev.profile_enable(False)
 
     # ---- metric #2: self-play games/sec (each rank drives its own GPU; games shard
     # embarrassingly, no collective on the data path)
     sp = None
     if args.selfplay_seconds > 0 and os.path.exists(SELFPLAY_BIN):
-        wpath = f"/tmp/nsg_bench_weights_{os.getpid() if not distributed else 'shared'}.nsgw"
-        if rank == 0:
-            with open(wpath, "wb") as f:
-                f.write(blob)
+        import tempfile
+        fd, wpath = tempfile.mkstemp(prefix=f"nsg_bench_weights_r{rank}_", suffix=".nsgw")
+        with os.fdopen(fd, "wb") as f:  # every rank writes its own copy of the broadcast bytes
+            f.write(blob)
         barrier()
         ev.close()  # free this process's evaluator before the self-play process allocates its own
         mine = selfplay_leg(wpath, local_rank, args.selfplay_seconds, args.selfplay_threads, args.precision,
                             games_per_group=args.selfplay_games_per_group)
-        keys = ("games_per_sec", "moves_per_sec", "playouts_per_sec", "evals_per_sec", "games_finished", "concurrent_games")
+        try:
+            os.remove(wpath)
+        except OSError:
+            pass
+        keys = ("games_per_sec", "games_per_sec_window", "moves_per_sec", "playouts_per_sec", "evals_per_sec",
+                "games_finished", "concurrent_games")
         # every rank takes part in every collective, whether its self-play process failed or not
         failed = 1.0 if "error" in mine else 0.0
         if distributed:
@@ -248,21 +339,15 @@ def main():
         if failed:
             sp = {"error": mine.get("error", "the self-play process failed on another rank"), "ranks_failed": int(failed)}
         else:
-            est = (tot["moves_per_sec"] / mine["avg_game_length"]) if mine["avg_game_length"] > 0 else None
-            sp = dict(tot, games_per_sec_steady_state_estimate=est, avg_batch=mine["avg_batch"], cache_hit_ratio=mine["cache_hit_ratio"],
-                      avg_game_length=mine["avg_game_length"], playouts_per_move=mine["playouts_per_move"],
-                      threads_per_gpu=mine["threads"], seconds=mine["seconds"],
+            sp = dict(tot, **{k: mine[k] for k in ("avg_batch", "cache_hit_ratio", "avg_game_length", "playouts_per_move",
+                                                   "seconds", "window_seconds") if k in mine},
+                      threads_per_gpu=mine.get("threads"),
                       note="AlphaZero-mode self-play from startpos on this build's own shogi core; synthetic "
-                           "(untrained) weights, so games end early by repetition and the evaluation cache "
-                           "hits often: games/sec is a plumbing number, evals/playouts per sec are the load; "
-                           "games_per_sec is finished/elapsed from a cold start (saveworker.cc:135-137), the "
-                           "estimate is moves_per_sec / avg_game_length")
+                           "(untrained) weights, so games end early by repetition: games/sec is a plumbing number, "
+                           "evals/playouts per sec are the load.  games_per_sec = finished / elapsed from a cold "
+                           "start (saveworker.cc:135-137); games_per_sec_window = games finished in the second "
+                           "half of the run / its length (the cold start excluded)")
         barrier()
-        if rank == 0:
-            try:
-                os.remove(wpath)
-            except OSError:
-                pass
         ev = None
 
     out = None
@@ -274,21 +359,28 @@ def main():
         conv_ms = prof["trunk_ms_total"] / max(prof["trunk_launches"], 1)
         achieved = conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
+        pmc, pmc_file = pmc_summary(args, B)
+        what = {"startpos": "the initial position in every slot (bench/batchsize.cc:47-59)",
+                "distinct": "B distinct positions of random-playout games", "synthetic": "seeded random bitboards"}
         out = {
             "metric": "NN evals/sec at batch=512" if B == 512 else f"NN evals/sec at batch={B}",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
+            "value_is": "device-resident rate (bitboards in HBM, outputs left in HBM); the reference's own "
+                        "PCIe-inclusive definition is reference_metric.evals_per_sec",
             "config": {"workload": f"batch={B} x {blocks}-block x {channels}-channel policy/value/draw "
                                    f"resnet, 86 feature planes, device-resident bitboards -> planes -> "
-                                   f"trunk -> heads (BASELINE configs[2] evaluator leg)",
-                       "batch_per_gpu": B, "net": args.net, "precision": args.precision,
+                                   f"trunk -> heads (BASELINE configs[2] evaluator leg); input: {what[args.positions]}",
+                       "batch_per_gpu": B, "net": args.net, "precision": args.precision, "positions": args.positions,
                        "parallelism": f"{world} independent evaluators (positions sharded, no data-path collective)",
                        "weights": "synthetic He-normal seed 0, BN folded, broadcast from rank 0"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": conv_traffic_bytes(args, B),
-                         "mfma_pipe_busy_frac_pmc": conv_mfma_busy(args, B),
+                         "frac": achieved / peak, "traffic": conv_traffic_bytes(pmc),
+                         "traffic_source": (f"{pmc_file} (committed rocprofv3 --pmc passes of this workload, NOT "
+                                            f"measured by this run)" if pmc_file else None),
+                         "mfma_pipe_busy_frac_pmc": conv_mfma_busy(pmc),
                          "mfma_flops_executed_per_algorithmic_flop": MFMA_UNITS[args.precision],
                          "kernel": "tileKernel<kConv> (3x3 conv F->F, bias+residual+ReLU fused)",
                          "avg_launch_ms": conv_ms, "launches_timed": prof["trunk_launches"],
@@ -298,53 +390,66 @@ def main():
             "forward_ms_hip_events": prof["forward_ms_total"] / max(prof["forwards"], 1),
             "device": info["device_name"], "compute_units": info["compute_units"],
         }
+        if sustained is not None:
+            out["sustained_evals_per_sec"] = sustained["evals_per_sec"]
+            sc = sustained["conv_avg_launch_ms"]
+            sustained["conv_frac_of_peak"] = conv_flops_launch / (sc * 1e-3) / 1e12 / peak if sc > 0 else None
+            out["sustained"] = sustained
         if sp is not None:
             out["selfplay"] = sp
         if not args.no_host_path and world == 1:
             ev = nsg.Evaluator(local_rank, B, 86, precision=args.precision)
             ev.load_memory(blob)
-            # the reference's own definition: computeBlocking incl. H2D/D2H (batchsize.cc:61-79)
             pol = np.empty((B, 2187), np.float32)
             win = np.empty(B, np.float32)
             drw = np.empty(B, np.float32)
-            for _ in range(2):
-                ev.compute_blocking(bb, policy=pol, win=win, draw=drw)
-            reps = max(3, args.steps // 2)
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                ev.compute_blocking(bb, policy=pol, win=win, draw=drw)
-            out["host_path_evals_per_sec"] = B * reps / (time.perf_counter() - t1)
+            secs = max(args.sustain_seconds, 1.0)
+            # the reference's own definition: 4 warm-ups, then back-to-back computeBlocking incl.
+            # H2D/D2H on the initial position replicated B times (batchsize.cc:47-79)
+            start = bb if args.positions == "startpos" else nsg.positions.startpos_batch(B)
+            for _ in range(4):
+                ev.compute_blocking(start, policy=pol, win=win, draw=drw)
+            rate, n, took = held_rate(lambda: ev.compute_blocking(start, policy=pol, win=win, draw=drw), B,
+                                      lambda: None, secs)
+            ref = {"definition": "bench/batchsize.cc:61-79: BatchSize * Repeat / wall over back-to-back "
+                                 "computeBlocking (H2D + planes + net + D2H + sync), 4 warm-ups, the initial "
+                                 "position in every slot",
+                   "evals_per_sec": rate, "repeat": n, "seconds": took}
+            ref["fraction_of_device_resident"] = rate / (sustained["evals_per_sec"] if sustained else value)
+            # the B-distinct variant of both rates (real positions of random-playout games)
+            other = positions("distinct" if args.positions != "distinct" else "startpos")
+            label = "distinct_positions" if args.positions != "distinct" else "startpos"
+            rate, n, took = held_rate(lambda: ev.compute_blocking(other, policy=pol, win=win, draw=drw), B,
+                                      lambda: None, secs)
+            ref[f"evals_per_sec_{label}"] = rate
+            ev.upload_features(other)
+            rate, n, took = held_rate(lambda: ev.forward_resident(B), B, torch.cuda.synchronize, secs)
+            out[f"device_resident_evals_per_sec_{label}"] = rate
+            out["reference_metric"] = ref
+            out["host_path_evals_per_sec"] = ref["evals_per_sec"]
             # the same with the legal-move lookup on the device: 80 legal moves per
             # position, softmax priors returned -- D2H shrinks from 8748 B to 320 B per position
             rng = np.random.default_rng(1)
             off = (np.arange(B + 1) * 80).astype(np.uint32)
             idx = rng.integers(0, 2187, size=B * 80).astype(np.uint16)
             vals = np.empty(B * 80, np.float32)
-            for _ in range(2):
-                ev.compute_gather_blocking(bb, idx, off, softmax=True, values=vals, win=win, draw=drw)
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                ev.compute_gather_blocking(bb, idx, off, softmax=True, values=vals, win=win, draw=drw)
-            out["host_path_device_gather_evals_per_sec"] = B * reps / (time.perf_counter() - t1)
+            rate, n, took = held_rate(lambda: ev.compute_gather_blocking(start, idx, off, softmax=True, values=vals,
+                                                                         win=win, draw=drw), B, lambda: None, min(secs, 2.0))
+            out["host_path_device_gather_evals_per_sec"] = rate
+            ev.close()
             # the evaluator at the other batch sizes the survey asks for (device-resident)
             if B == 512 and args.net == "20x256":
                 big = nsg.Evaluator(local_rank, 1024, 86, precision=args.precision)
                 big.load_memory(blob)
-                bbig = nsg.synth.random_batch(1024, 86, seed=nsg.synth.SEED + 1, distinct=True)
-                big.upload_features(bbig)
+                big.upload_features(nsg.positions.startpos_batch(1024))
                 by_batch = {}
-                for nb in (1, 64, 128, 1024):  # 128 = the engine's default BatchSize (context.h:79)
-                    big.forward_resident(nb)
-                    torch.cuda.synchronize()
-                    k = max(4, min(200, int(20 * 512 / nb) // 8))
-                    t1 = time.perf_counter()
-                    for _ in range(k):
-                        big.forward_resident(nb)
-                    torch.cuda.synchronize()
-                    by_batch[str(nb)] = nb * k / (time.perf_counter() - t1)
+                for nb in (1, 64, 128, 256, 1024):  # 128 = the engine's default BatchSize (context.h:79)
+                    rate, n, took = held_rate(lambda: big.forward_resident(nb), nb, torch.cuda.synchronize, 1.0)
+                    by_batch[str(nb)] = rate
                 by_batch["512"] = value
                 out["evals_per_sec_by_batch"] = by_batch
                 big.close()
+            out["roofline_extract"] = extract_roofline(nsg, bb, B)
         if not args.no_host_path and world == 1:
             out["other_precisions_evals_per_sec"] = {
                 p: quick_rate(nsg, local_rank, blob, bb, B, p) for p in ("fp32", "f16x3", "f16m8", "fp16", "bf16")

@@ -98,6 +98,14 @@ int nsg_convert_onnx(const void* onnx, size_t size, void* dst, size_t capacity,
 int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size);
 int nsg_load_device_blob(nsg_evaluator* ev, const void* device_blob,
                          size_t size);
+/* Replaces the model re-read of every further executor: the reference builds
+ * NumGPUs x threads-per-GPU executors that each load the file again
+ * (src/selfplay/main.cc:189-195, src/mcts/manager.cc:168-179,
+ * src/mcts/evaluationworker.cc:83-86).  Here `ev` adopts the network `src`
+ * has loaded: on the same device both share one copy of the packed weights,
+ * on another device `ev` takes a peer copy (hipMemcpyPeer over xGMI).  Same
+ * precision and plane count required; `src` may be destroyed afterwards. */
+int nsg_load_shared(nsg_evaluator* ev, nsg_evaluator* src);
 
 /* Replaces infer::Infer::computeNonBlocking(const ml::FeatureBitboard*
  * Features, std::size_t BatchSize, float* DstPolicy, float* DstWinRate,

@@ -34,6 +34,8 @@
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -78,6 +80,10 @@ class BatchPipeline {
         , Buffers(NumBuffers)
         , FillSeq(0)
         , Closed(false) {
+        // one buffer filling while every executor has one in flight; fewer deadlocks openNext()
+        if (Exec.empty() || NumBuffers < Exec.size() + 1) {
+            throw std::invalid_argument("BatchPipeline: NumBuffers must be at least Executors.size() + 1");
+        }
         for (auto& B : Buffers) {
             B.Features = static_cast<ml::FeatureBitboard*>(
                 alloc(BatchMax * FeatSize * sizeof(ml::FeatureBitboard)));
@@ -125,8 +131,18 @@ class BatchPipeline {
             Buffer& B = Buffers[Seq % Buffers.size()];
             if (B.Phase.load(std::memory_order_acquire) == kFilling &&
                 B.Seq.load(std::memory_order_acquire) == Seq) {
-                const uint64_t Old = B.State.fetch_add(1, std::memory_order_acq_rel);
-                if (!(Old & kSealed) && (Old & kCountMask) < BatchMax) {
+                // The generation lives in the State word and the slot is taken by compare-exchange,
+                // so a producer that read FillSeq one buffer cycle ago can never take (or even
+                // count) a slot of the buffer's next generation.
+                uint64_t Old = B.State.load(std::memory_order_acquire);
+                bool Taken = false;
+                while ((Old >> kGenShift) == (Seq & kGenMask) && !(Old & kSealed) && (Old & kCountMask) < BatchMax) {
+                    if (B.State.compare_exchange_weak(Old, Old + 1, std::memory_order_acq_rel, std::memory_order_acquire)) {
+                        Taken = true;
+                        break;
+                    }
+                }
+                if (Taken) {
                     const uint32_t Idx = (uint32_t)(Old & kCountMask);
                     B.Tags[Idx] = Tag;
                     Out->Features = B.Features + (std::size_t)Idx * FeatSize;
@@ -134,7 +150,7 @@ class BatchPipeline {
                     Out->Index = Idx;
                     return true;
                 }
-                // full or sealed: wake the evaluation thread and wait for the next buffer
+                // full, sealed or recycled: wake the evaluation thread and wait for the next buffer
                 wakeEvaluator();
             }
             std::unique_lock<std::mutex> Lock(Mutex);
@@ -227,6 +243,8 @@ class BatchPipeline {
     enum : uint32_t { kFree = 0, kFilling = 1, kInFlight = 2, kFeeding = 3 };
     static constexpr uint64_t kSealed = 1ULL << 32;
     static constexpr uint64_t kCountMask = 0xffffffffULL;
+    static constexpr int kGenShift = 33; // State = generation (FillSeq, 31 bits) | sealed | slots handed out
+    static constexpr uint64_t kGenMask = 0x7fffffffULL;
 
     struct Buffer {
         ml::FeatureBitboard* Features = nullptr;
@@ -234,7 +252,7 @@ class BatchPipeline {
         float* Win = nullptr;
         float* Draw = nullptr;
         std::vector<LeafTag> Tags;
-        std::atomic<uint64_t> State{0};     // low 32: slots handed out; bit 32: sealed
+        std::atomic<uint64_t> State{0};     // low 32: slots handed out; bit 32: sealed; above: generation
         std::atomic<uint64_t> Committed{0}; // slots completely written
         std::atomic<uint32_t> Phase{kFree};
         std::atomic<uint64_t> Seq{0};       // FillSeq value this buffer currently serves
@@ -294,8 +312,10 @@ class BatchPipeline {
         while (NB.Phase.load(std::memory_order_acquire) != kFree) {
             std::this_thread::yield();
         }
-        NB.State.store(0, std::memory_order_relaxed);
+        // Committed first: a producer can commit only after taking a slot of the new generation,
+        // which it can see only through the release store of State below
         NB.Committed.store(0, std::memory_order_relaxed);
+        NB.State.store((Next & kGenMask) << kGenShift, std::memory_order_release);
         NB.Seq.store(Next, std::memory_order_release);
         NB.Phase.store(kFilling, std::memory_order_release);
         FillSeq.store(Next, std::memory_order_release);
@@ -350,11 +370,12 @@ class BatchPipeline {
     void* alloc(std::size_t Bytes) {
         void* P = nullptr;
         if (posix_memalign(&P, 4096, Bytes == 0 ? 4096 : Bytes) != 0) {
-            return nullptr;
+            throw std::bad_alloc();
         }
         std::memset(P, 0, Bytes);
-        if (Pinned) {
-            nsg_host_register(P, Bytes); // evaluator.cc:94-105
+        // evaluator.cc:94-105; only what was really page-locked is unregistered later
+        if (Pinned && nsg_host_register(P, Bytes) == NSG_OK) {
+            Registered.push_back(P);
         }
         return P;
     }
@@ -363,8 +384,12 @@ class BatchPipeline {
         if (!P) {
             return;
         }
-        if (Pinned) {
-            nsg_host_unregister(P);
+        for (std::size_t I = 0; I < Registered.size(); ++I) {
+            if (Registered[I] == P) {
+                nsg_host_unregister(P);
+                Registered.erase(Registered.begin() + (std::ptrdiff_t)I);
+                break;
+            }
         }
         std::free(P);
     }
@@ -374,6 +399,7 @@ class BatchPipeline {
     const std::size_t BatchMax;
     FeedFn Feed;
     const bool Pinned;
+    std::vector<void*> Registered; // buffers nsg_host_register accepted
 
     std::vector<Buffer> Buffers;
     std::atomic<uint64_t> FillSeq;

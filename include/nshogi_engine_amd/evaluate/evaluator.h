@@ -3,20 +3,32 @@
 // and thin forwarder to the executor.
 //
 // Same public interface as /root/reference/src/evaluate/evaluator.h:26-86.
-// The only behavioural difference from evaluator.cc:31-149 is the pinning call:
-// hipHostRegister (through nsg_host_register) where the reference calls
-// cudaHostRegister (evaluator.cc:94-105, 110-115).  NUMA placement is the
-// reference's own optional libnuma path and is not restated (libnuma is not in
-// this image); allocation falls back to std::malloc exactly as
-// evaluator.cc:136-138 does when NUMA is off.
+// Differences from evaluator.cc:31-149:
+//   * pinning is hipHostRegister (through nsg_host_register) where the reference calls
+//     cudaHostRegister (evaluator.cc:94-105, 110-115), tracked per buffer so that exactly
+//     what was page-locked is unregistered;
+//   * NUMA placement (the reference's optional NUMA_ENABLED build, evaluator.cc:46-76,127-149:
+//     node = AvailableNodes[ThreadId % count], sched_setaffinity to the node's CPUs,
+//     numa_alloc_onnode) needs no libnuma here: the node list and CPU masks come from
+//     /sys/devices/system/node, the thread is bound with sched_setaffinity, and the buffers are
+//     first-touched right after, which places their pages on that node under the default local
+//     allocation policy.  Off unless asked for (NumaPlacement = true), like the reference's build
+//     flag; a machine with one node is left alone.
 #ifndef NSG_EVALUATE_EVALUATOR_H
 #define NSG_EVALUATE_EVALUATOR_H
 
 #include "../infer/infer.h"
 #include "../../nsg.h"
 
+#include <sched.h>
+
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
 
 namespace nshogi {
 namespace engine {
@@ -26,41 +38,47 @@ class Evaluator {
  public:
     // PinMemory: page-lock the four buffers (the reference does so when built
     // with CUDA_ENABLED); pass false for the CPU executors.
-    Evaluator(std::size_t /*ThreadId*/, std::size_t FeatureSize,
-              std::size_t BatchSize, infer::Infer* In, bool PinMemory = true)
+    Evaluator(std::size_t ThreadId, std::size_t FeatureSize,
+              std::size_t BatchSize, infer::Infer* In, bool PinMemory = true,
+              bool NumaPlacement = false)
         : PInfer(In)
         , MyFeatureSize(FeatureSize)
         , BatchSizeMax(BatchSize)
-        , Pinned(false) {
-        FeatureBitboards = static_cast<ml::FeatureBitboard*>(
-            allocateMemoryByNumaIfAvailable(BatchSizeMax * MyFeatureSize *
-                                            sizeof(ml::FeatureBitboard)));
-        Policy = static_cast<float*>(allocateMemoryByNumaIfAvailable(
-            ml::MoveIndexMax * BatchSizeMax * sizeof(float)));
-        WinRate = static_cast<float*>(
-            allocateMemoryByNumaIfAvailable(BatchSizeMax * sizeof(float)));
-        DrawRate = static_cast<float*>(
-            allocateMemoryByNumaIfAvailable(BatchSizeMax * sizeof(float)));
+        , Pinned(false)
+        , MyNumaId(-1) {
+        if (NumaPlacement) {
+            MyNumaId = bindToNumaNode(ThreadId); // evaluator.cc:46-76
+        }
+        const std::size_t Sizes[4] = {
+            BatchSizeMax * MyFeatureSize * sizeof(ml::FeatureBitboard),
+            ml::MoveIndexMax * BatchSizeMax * sizeof(float),
+            BatchSizeMax * sizeof(float), BatchSizeMax * sizeof(float)};
+        void* Mem[4];
+        for (int I = 0; I < 4; ++I) {
+            Mem[I] = allocateMemoryByNumaIfAvailable(Sizes[I]);
+            if (!Mem[I]) {
+                for (int J = 0; J < I; ++J) std::free(Mem[J]);
+                throw std::bad_alloc();
+            }
+            std::memset(Mem[I], 0, Sizes[I]); // first touch: pages land on this thread's node
+        }
+        FeatureBitboards = static_cast<ml::FeatureBitboard*>(Mem[0]);
+        Policy = static_cast<float*>(Mem[1]);
+        WinRate = static_cast<float*>(Mem[2]);
+        DrawRate = static_cast<float*>(Mem[3]);
         if (PinMemory) {
-            Pinned =
-                nsg_host_register(FeatureBitboards,
-                                  BatchSizeMax * MyFeatureSize *
-                                      sizeof(ml::FeatureBitboard)) == NSG_OK &&
-                nsg_host_register(Policy, ml::MoveIndexMax * BatchSizeMax *
-                                              sizeof(float)) == NSG_OK &&
-                nsg_host_register(WinRate, BatchSizeMax * sizeof(float)) ==
-                    NSG_OK &&
-                nsg_host_register(DrawRate, BatchSizeMax * sizeof(float)) ==
-                    NSG_OK;
+            Pinned = true;
+            for (int I = 0; I < 4; ++I) {
+                Registered[I] = nsg_host_register(Mem[I], Sizes[I]) == NSG_OK;
+                Pinned = Pinned && Registered[I];
+            }
         }
     }
 
     ~Evaluator() {
-        if (Pinned) {
-            nsg_host_unregister(FeatureBitboards);
-            nsg_host_unregister(Policy);
-            nsg_host_unregister(WinRate);
-            nsg_host_unregister(DrawRate);
+        void* Mem[4] = {FeatureBitboards, Policy, WinRate, DrawRate};
+        for (int I = 0; I < 4; ++I) {
+            if (Registered[I]) nsg_host_unregister(Mem[I]);
         }
         freeMemory(reinterpret_cast<void**>(&FeatureBitboards), 0);
         freeMemory(reinterpret_cast<void**>(&Policy), 0);
@@ -113,6 +131,58 @@ class Evaluator {
         return Pinned;
     }
 
+    // NUMA node this evaluator's thread and buffers were placed on; -1 = no placement.
+    int numaNode() const {
+        return MyNumaId;
+    }
+
+    // CPU lists of the machine's NUMA nodes that have CPUs, from /sys/devices/system/node.
+    static std::vector<std::vector<int>> numaNodeCpus() {
+        std::vector<std::vector<int>> Nodes;
+        for (int Node = 0; Node < 1024; ++Node) {
+            const std::string Path = "/sys/devices/system/node/node" + std::to_string(Node) + "/cpulist";
+            std::FILE* F = std::fopen(Path.c_str(), "r");
+            if (!F) {
+                if (Node > 64) break; // node numbers may be sparse, but not that sparse
+                continue;
+            }
+            char Buf[4096] = {0};
+            const std::size_t Got = std::fread(Buf, 1, sizeof(Buf) - 1, F);
+            std::fclose(F);
+            std::vector<int> Cpus; // "0-31,64-95"
+            std::size_t P = 0;
+            while (P < Got) {
+                char* End = nullptr;
+                const long A = std::strtol(Buf + P, &End, 10);
+                if (End == Buf + P) break;
+                long B = A;
+                P = (std::size_t)(End - Buf);
+                if (Buf[P] == '-') {
+                    B = std::strtol(Buf + P + 1, &End, 10);
+                    P = (std::size_t)(End - Buf);
+                }
+                for (long C = A; C <= B; ++C) Cpus.push_back((int)C);
+                if (Buf[P] == ',') ++P; else break;
+            }
+            if (!Cpus.empty()) Nodes.push_back(std::move(Cpus));
+        }
+        return Nodes;
+    }
+
+    // Binds the calling thread to the CPUs of node Nodes[ThreadId % count]; returns the index, or
+    // -1 when the machine has a single node or the call fails.
+    static int bindToNumaNode(std::size_t ThreadId) {
+        const auto Nodes = numaNodeCpus();
+        if (Nodes.size() < 2) return -1;
+        const std::size_t Mine = ThreadId % Nodes.size();
+        cpu_set_t Set;
+        CPU_ZERO(&Set);
+        for (int C : Nodes[Mine]) {
+            if (C < CPU_SETSIZE) CPU_SET(C, &Set);
+        }
+        return sched_setaffinity(0, sizeof(Set), &Set) == 0 ? (int)Mine : -1;
+    }
+
     void* allocateMemoryByNumaIfAvailable(std::size_t Size) const {
         // 64-byte alignment: ml::FeatureBitboard needs 16, DMA likes cache lines
         void* Memory = nullptr;
@@ -137,6 +207,8 @@ class Evaluator {
     const std::size_t MyFeatureSize;
     const std::size_t BatchSizeMax;
     bool Pinned;
+    bool Registered[4] = {false, false, false, false};
+    int MyNumaId;
 };
 
 } // namespace evaluate

@@ -65,6 +65,13 @@ class Hip : public Infer {
         check(RC);
     }
 
+    // Extension: adopt the network `Src` has loaded instead of reading the model file again
+    // (the reference's G x T executors each call load(), selfplay/main.cc:189-195): executors
+    // on one device share one copy of the weights, another device takes a peer copy over xGMI.
+    void loadShared(Hip& Src) {
+        check(nsg_load_shared(Handle, Src.Handle));
+    }
+
     void computeNonBlocking(const ml::FeatureBitboard* Features,
                             std::size_t BatchSize, float* DstPolicy,
                             float* DstWinRate, float* DstDrawRate) override {

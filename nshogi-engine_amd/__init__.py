@@ -22,13 +22,14 @@ from .capi import (  # noqa: F401
     PRECISION_FP16,
     PRECISION_BF16,
     PRECISION_F16X3,
+    PRECISION_F16M8,
     MOVE_INDEX_MAX,
     NUM_SQUARES,
 )
-from . import weights, synth, dist, onnx_io, teacher  # noqa: F401
+from . import weights, synth, dist, onnx_io, teacher, positions  # noqa: F401
 
 __all__ = [
     "NsgError", "Evaluator", "CpuExecutor", "extract_bits", "convert_onnx", "load_library",
-    "library_path", "weights", "synth", "dist", "onnx_io", "teacher", "PRECISION_FP32", "PRECISION_FP16",
-    "PRECISION_BF16", "PRECISION_F16X3", "MOVE_INDEX_MAX", "NUM_SQUARES",
+    "library_path", "weights", "synth", "dist", "onnx_io", "teacher", "positions", "PRECISION_FP32", "PRECISION_FP16",
+    "PRECISION_BF16", "PRECISION_F16X3", "PRECISION_F16M8", "MOVE_INDEX_MAX", "NUM_SQUARES",
 ]

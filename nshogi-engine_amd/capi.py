@@ -14,6 +14,7 @@ PRECISION_FP32 = 0
 PRECISION_FP16 = 1
 PRECISION_BF16 = 2
 PRECISION_F16X3 = 3
+PRECISION_F16M8 = 4
 MOVE_INDEX_MAX = 2187
 NUM_SQUARES = 81
 BITBOARD_BYTES = 16
@@ -75,6 +76,7 @@ def load_library():
     lib.nsg_convert_onnx.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
     lib.nsg_load_memory.argtypes = [vp, vp, sz]
     lib.nsg_load_device_blob.argtypes = [vp, vp, sz]
+    lib.nsg_load_shared.argtypes = [vp, vp]
     for name in ("nsg_compute_nonblocking", "nsg_compute_blocking"):
         getattr(lib, name).argtypes = [vp, vp, sz, vp, vp, vp]
     lib.nsg_await.argtypes = [vp]
@@ -136,8 +138,12 @@ class Evaluator:
         self.num_channels = int(num_channels)
         _check(self._lib.nsg_create(int(gpu_id), int(batch_size_max), int(num_channels),
                                     ctypes.byref(self._h)))
-        prec = _PREC_NAMES[precision] if isinstance(precision, str) else int(precision)
-        _check(self._lib.nsg_set_precision(self._h, prec))
+        try:
+            prec = _PREC_NAMES[precision] if isinstance(precision, str) else int(precision)
+            _check(self._lib.nsg_set_precision(self._h, prec))
+        except Exception:
+            self.close()  # do not leak the handle (device buffers, streams) on a bad precision
+            raise
         self._pending = None
 
     def close(self):
@@ -162,6 +168,10 @@ class Evaluator:
     def load_device_blob(self, device_ptr, size):
         _check(self._lib.nsg_load_device_blob(self._h, ctypes.c_void_p(int(device_ptr)), int(size)))
 
+    def load_shared(self, src):
+        """nsg_load_shared: adopt the network another evaluator has loaded (no file re-read)."""
+        _check(self._lib.nsg_load_shared(self._h, src._h))
+
     def _outputs(self, n, policy, win, draw):
         if policy is None:
             policy = np.empty((n, MOVE_INDEX_MAX), dtype=np.float32)
@@ -174,9 +184,15 @@ class Evaluator:
                 raise ValueError("output buffers must be contiguous float32 of sufficient size")
         return policy, win, draw
 
+    def _batch(self, a, batch_size):
+        n = a.shape[0] if batch_size is None else int(batch_size)
+        if n < 1 or n > a.shape[0]:
+            raise ValueError(f"batch_size {n} outside [1, {a.shape[0]}] (rows of the feature array)")
+        return n
+
     def compute_nonblocking(self, features, batch_size=None, policy=None, win=None, draw=None):
         a = _features_array(features, self.num_channels)
-        n = a.shape[0] if batch_size is None else int(batch_size)
+        n = self._batch(a, batch_size)
         policy, win, draw = self._outputs(n, policy, win, draw)
         _check(self._lib.nsg_compute_nonblocking(self._h, _ptr(a), n, _ptr(policy), _ptr(win),
                                                  _ptr(draw)))
@@ -185,7 +201,7 @@ class Evaluator:
 
     def compute_blocking(self, features, batch_size=None, policy=None, win=None, draw=None):
         a = _features_array(features, self.num_channels)
-        n = a.shape[0] if batch_size is None else int(batch_size)
+        n = self._batch(a, batch_size)
         policy, win, draw = self._outputs(n, policy, win, draw)
         _check(self._lib.nsg_compute_blocking(self._h, _ptr(a), n, _ptr(policy), _ptr(win),
                                               _ptr(draw)))
@@ -199,12 +215,20 @@ class Evaluator:
         off = np.ascontiguousarray(move_offsets, dtype=np.uint32)
         idx = np.ascontiguousarray(move_indices, dtype=np.uint16)
         n = off.shape[0] - 1
+        total = int(off[-1]) if n >= 0 else 0
+        if n < 1 or n > a.shape[0]:
+            raise ValueError(f"move_offsets describes {n} positions, the feature array has {a.shape[0]}")
+        if idx.size < total:
+            raise ValueError(f"move_indices holds {idx.size} entries, move_offsets[-1] = {total}")
         if values is None:
-            values = np.full((int(off[-1]),), np.nan, dtype=np.float32)
+            values = np.full((total,), np.nan, dtype=np.float32)
         if win is None:
             win = np.full((n,), np.nan, dtype=np.float32)
         if draw is None:
             draw = np.full((n,), np.nan, dtype=np.float32)
+        for arr, cnt, name in ((values, total, "values"), (win, n, "win"), (draw, n, "draw")):
+            if arr.dtype != np.float32 or not arr.flags["C_CONTIGUOUS"] or arr.size < cnt:
+                raise ValueError(f"{name} must be contiguous float32 with at least {cnt} elements")
         _check(self._lib.nsg_compute_gather_blocking(self._h, _ptr(a), n, _ptr(idx), _ptr(off),
                                                      1 if softmax else 0, _ptr(values), _ptr(win), _ptr(draw)))
         return values, win, draw

@@ -66,6 +66,38 @@ class ChecksumInfer : public infer::Infer {
 } // namespace
 
 int main(int Argc, char* Argv[]) {
+    if (Argc >= 2 && std::string(Argv[1]) == "numa") {
+        // Evaluator's NUMA placement (evaluator.cc:46-76 without libnuma): the machine's nodes, and
+        // a few evaluators created with placement on -- each must report the node it was bound to
+        const auto Nodes = evaluate::Evaluator::numaNodeCpus();
+        std::cout << "nodes " << Nodes.size();
+        for (const auto& N : Nodes) std::cout << " " << N.size();
+        std::cout << std::endl;
+        ChecksumInfer Exec;
+        for (std::size_t T = 0; T < 3; ++T) {
+            evaluate::Evaluator Ev(T, kC, 4, &Exec, false, true);
+            const int Want = Nodes.size() < 2 ? -1 : (int)(T % Nodes.size());
+            if (Ev.numaNode() != Want) { std::cout << "wrong node " << Ev.numaNode() << " want " << Want << std::endl; return 1; }
+            if (Want >= 0) {
+                cpu_set_t Set;
+                sched_getaffinity(0, sizeof(Set), &Set);
+                for (int C : Nodes[(std::size_t)Want]) if (C < CPU_SETSIZE && !CPU_ISSET(C, &Set)) { std::cout << "cpu not in mask" << std::endl; return 1; }
+                if (CPU_COUNT(&Set) != (int)Nodes[(std::size_t)Want].size()) { std::cout << "mask too wide" << std::endl; return 1; }
+            }
+        }
+        std::cout << "numa ok" << std::endl;
+        return 0;
+    }
+    if (Argc >= 2 && std::string(Argv[1]) == "badpool") { // NumBuffers < Depth + 1 must be refused, not deadlock
+        ChecksumInfer A, B;
+        try {
+            evaluate::BatchPipeline P({&A, &B}, kC, 8, 2, 1, [](const evaluate::LeafTag&, const float*, float, float) {}, false);
+        } catch (const std::invalid_argument& E) {
+            std::cout << "refused: " << E.what() << std::endl;
+            return 0;
+        }
+        return 1;
+    }
     if (Argc < 8) {
         std::cerr << "usage: pipeline_test checksum|hip <leaves> <producers> <batch> <buffers> <depth> <feeders> [weights]" << std::endl;
         return 2;

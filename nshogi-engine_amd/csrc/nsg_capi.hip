@@ -50,6 +50,14 @@ int fail(int code, const char* fmt, ...) {
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
     int alloc(size_t n, bool zero) {
         release();
         if (n == 0) n = 16;
@@ -78,6 +86,33 @@ struct ConvLayer {
     DevBuf bias; // f32 [cout]
     int cin = 0; // padded input channels
     float accScale = 1.f; // 1 / (power-of-two weight scale), kF16x3 only
+};
+
+// Everything nsg_load* uploads: read-only after the load, so evaluators on one device share
+// one copy (nsg_load_shared) and evaluators on other devices take a peer copy of it.
+struct NetWeights {
+    int gpu = 0;
+    int prec = 0;
+    int F = 0, blocks = 0, vc = 0, vh = 0, cin = 0, cpad = 0, headsCout = 0, fc1K = 0;
+    uint64_t params = 0;
+    ConvLayer stem;
+    std::vector<ConvLayer> conv1, conv2;
+    // kF16m8 also holds the trunk in kF16x3 form: batches too small for full
+    // tiles (4 fragments per wave) run the kF16x3 small-tile kernels instead
+    ConvLayer stemX3;
+    std::vector<ConvLayer> conv1X3, conv2X3;
+    ConvLayer heads;
+    ConvLayer fc1;
+    DevBuf fc2W, fc2B;
+    ~NetWeights() {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        (void)hipSetDevice(gpu); // the buffers are released on the device that owns them
+        stem = ConvLayer(); stemX3 = ConvLayer(); heads = ConvLayer(); fc1 = ConvLayer();
+        conv1.clear(); conv2.clear(); conv1X3.clear(); conv2X3.clear();
+        fc2W.release(); fc2B.release();
+        if (cur >= 0) (void)hipSetDevice(cur);
+    }
 };
 
 // Parsed view of an NSGW v1 blob (DESIGN.md "Weight file").
@@ -193,16 +228,8 @@ struct nsg_evaluator {
     DevBuf hidden;        // [K slices][B][VH] f32 partial sums of the value MLP's first layer
     DevBuf scratch;       // debug read-back
 
-    ConvLayer stem;
-    std::vector<ConvLayer> conv1, conv2;
-    // kF16m8 evaluators also hold the trunk in kF16x3 form: batches too small for full
-    // tiles (4 fragments per wave) run the kF16x3 small-tile kernels instead
-    ConvLayer stemX3;
-    std::vector<ConvLayer> conv1X3, conv2X3;
+    std::shared_ptr<NetWeights> W; // shared by the evaluators of one device (nsg_load_shared)
     int lastTrunkPrec = -1; // precision the most recent forward ran its trunk in
-    ConvLayer heads;
-    ConvLayer fc1;
-    DevBuf fc2W, fc2B;
     DevBuf stamps;           // diagnostic builds: per-layer, per-workgroup cycle stamps
     DevBuf trunkLayers;      // persistent-trunk layer list (stem + 2 per block)
     int trunkLayerCount = 0;
@@ -326,9 +353,9 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     // kF16m8 runs full tiles only; smaller launch plans use the kF16x3 copy of the trunk
     const bool x3Fallback = (ev->prec == nsg::kF16m8 && plan.nfrag != 4);
     const int prec = x3Fallback ? (int)nsg::kF16x3 : ev->prec;
-    const ConvLayer& stem = x3Fallback ? ev->stemX3 : ev->stem;
-    const std::vector<ConvLayer>& conv1 = x3Fallback ? ev->conv1X3 : ev->conv1;
-    const std::vector<ConvLayer>& conv2 = x3Fallback ? ev->conv2X3 : ev->conv2;
+    const ConvLayer& stem = x3Fallback ? ev->W->stemX3 : ev->W->stem;
+    const std::vector<ConvLayer>& conv1 = x3Fallback ? ev->W->conv1X3 : ev->W->conv1;
+    const std::vector<ConvLayer>& conv2 = x3Fallback ? ev->W->conv2X3 : ev->W->conv2;
     if (off == 0) ev->lastTrunkPrec = prec;
     const size_t es = (size_t)nsg::elemSize(prec);
     auto act = [&](void* base, size_t rowElems) { return (void*)((unsigned char*)base + (size_t)off * rowElems * es); };
@@ -369,13 +396,13 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     float* policy = (float*)ev->policy.p + (size_t)off * NSG_MOVE_INDEX_MAX;
     void* vfeat = act(ev->vfeat.p, (size_t)ev->fc1K);
     float* hidden = (float*)ev->hidden.p + (size_t)off * ev->vh;
-    NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p, policy, vfeat, count, ev->F,
-                             ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, hprec, s));
+    NSG_HIP(nsg::launchHeads(x, ev->W->heads.w.p, (const float*)ev->W->heads.bias.p, policy, vfeat, count, ev->F,
+                             ev->headsCout, ev->vc, ev->fc1K, ev->W->heads.accScale, hprec, s));
     const size_t partStride = (size_t)ev->batchMax * ev->vh; // floats between the K slices' partial sums
-    NSG_HIP(nsg::launchDense(vfeat, ev->fc1.w.p, (const float*)ev->fc1.bias.p, hidden, count, ev->fc1K,
-                             ev->vh, partStride, ev->fc1.accScale, hprec, s));
-    NSG_HIP(nsg::launchValueOut(hidden, (const float*)ev->fc1.bias.p, nsg::denseSplits(ev->fc1K, hprec), partStride,
-                                (const float*)ev->fc2W.p, (const float*)ev->fc2B.p,
+    NSG_HIP(nsg::launchDense(vfeat, ev->W->fc1.w.p, (const float*)ev->W->fc1.bias.p, hidden, count, ev->fc1K,
+                             ev->vh, partStride, ev->W->fc1.accScale, hprec, s));
+    NSG_HIP(nsg::launchValueOut(hidden, (const float*)ev->W->fc1.bias.p, nsg::denseSplits(ev->fc1K, hprec), partStride,
+                                (const float*)ev->W->fc2W.p, (const float*)ev->W->fc2B.p,
                                 (float*)ev->value.p + off, (float*)ev->draw.p + off, count, ev->vh, s));
     return NSG_OK;
 }
@@ -459,14 +486,14 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         void* x = (ev->blocks % 2 == 1) ? ev->act[2].p : ev->act[0].p;
         ev->trunkOut = x;
         ev->lastTrunkPrec = prec;
-        NSG_HIP(nsg::launchHeads(x, ev->heads.w.p, (const float*)ev->heads.bias.p, (float*)ev->policy.p,
-                                 ev->vfeat.p, B, ev->F, ev->headsCout, ev->vc, ev->fc1K, ev->heads.accScale, nsg::headPrecision(prec), s));
+        NSG_HIP(nsg::launchHeads(x, ev->W->heads.w.p, (const float*)ev->W->heads.bias.p, (float*)ev->policy.p,
+                                 ev->vfeat.p, B, ev->F, ev->headsCout, ev->vc, ev->fc1K, ev->W->heads.accScale, nsg::headPrecision(prec), s));
         const size_t partStride = (size_t)ev->batchMax * ev->vh;
-        NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->fc1.w.p, (const float*)ev->fc1.bias.p, (float*)ev->hidden.p,
-                                 B, ev->fc1K, ev->vh, partStride, ev->fc1.accScale, nsg::headPrecision(prec), s));
-        NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->fc1.bias.p,
-                                    nsg::denseSplits(ev->fc1K, nsg::headPrecision(prec)), partStride, (const float*)ev->fc2W.p,
-                                    (const float*)ev->fc2B.p, (float*)ev->value.p, (float*)ev->draw.p, B, ev->vh, s));
+        NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->W->fc1.w.p, (const float*)ev->W->fc1.bias.p, (float*)ev->hidden.p,
+                                 B, ev->fc1K, ev->vh, partStride, ev->W->fc1.accScale, nsg::headPrecision(prec), s));
+        NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->W->fc1.bias.p,
+                                    nsg::denseSplits(ev->fc1K, nsg::headPrecision(prec)), partStride, (const float*)ev->W->fc2W.p,
+                                    (const float*)ev->W->fc2B.p, (float*)ev->value.p, (float*)ev->draw.p, B, ev->vh, s));
     } else if (chains == 1) {
         int rc = enqueueChain(ev, 0, B, plan, s, true, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
         if (rc) return rc;
@@ -526,12 +553,58 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     return NSG_OK;
 }
 
+// Second half of every load: adopt the (possibly shared) weights and allocate this evaluator's own
+// activation buffers, sized for batchMax.
+int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
+    int rc;
+    const int prec = ev->prec;
+    const int es = nsg::elemSize(prec);
+    ev->W = std::move(W);
+    const NetWeights& N = *ev->W;
+    ev->F = N.F; ev->blocks = N.blocks; ev->vc = N.vc; ev->vh = N.vh;
+    ev->cpad = N.cpad; ev->headsCout = N.headsCout; ev->fc1K = N.fc1K; ev->params = N.params;
+    // activation buffers: whole workgroups of up to 2 boards
+    const size_t bpad = (size_t)roundUp(ev->batchMax, 2);
+    if ((rc = ev->planes.alloc(bpad * 81 * ev->cpad * es, true))) return rc;
+    for (int i = 0; i < 3; ++i)
+        if ((rc = ev->act[i].alloc(bpad * 81 * N.F * es, true))) return rc;
+    if ((rc = ev->vfeat.alloc((size_t)ev->batchMax * ev->fc1K * es, true))) return rc;
+    if ((rc = ev->hidden.alloc((size_t)ev->batchMax * N.vh * 4 * nsg::denseSplits(ev->fc1K, nsg::headPrecision(prec)), true))) return rc;
+    {   // persistent-trunk layer list, same buffer rotation as the per-layer path
+        const int nl = 1 + 2 * N.blocks;
+        std::vector<unsigned char> host((size_t)nl * nsg::trunkLayerBytes());
+        void* x = ev->act[0].p; void* y = ev->act[1].p; void* z = ev->act[2].p;
+        nsg::fillTrunkLayer(host.data(), 0, ev->planes.p, N.stem.w.p, (const float*)N.stem.bias.p,
+                            nullptr, x, ev->cpad, N.F, 1, N.stem.accScale);
+        for (int k = 0; k < N.blocks; ++k) {
+            nsg::fillTrunkLayer(host.data(), 1 + 2 * k, x, N.conv1[k].w.p, (const float*)N.conv1[k].bias.p,
+                                nullptr, y, N.F, N.F, 1, N.conv1[k].accScale);
+            nsg::fillTrunkLayer(host.data(), 2 + 2 * k, y, N.conv2[k].w.p, (const float*)N.conv2[k].bias.p,
+                                x, z, N.F, N.F, 1, N.conv2[k].accScale,
+                                prec == nsg::kF16m8 && k == N.blocks - 1);
+            void* t = x; x = z; z = t;
+        }
+        if ((rc = ev->trunkLayers.alloc(host.size(), false))) return rc;
+        NSG_HIP(hipMemcpy(ev->trunkLayers.p, host.data(), host.size(), hipMemcpyHostToDevice));
+        ev->trunkLayerCount = nl;
+        const char* env = getenv("NSG_TRUNK_KERNEL");
+        ev->useTrunkKernel = (env && env[0] == '1');
+    }
+    NSG_HIP(hipDeviceSynchronize());
+    ev->calibKey = -1; // a new network: re-measure the layer time for the chain stagger
+    ev->calibPending = false;
+    ev->loaded = true;
+    return NSG_OK;
+}
+
 int checkCompute(nsg_evaluator* ev, size_t n) {
     if (!ev) return fail(NSG_E_INVALID, "null evaluator");
     if (!ev->loaded) return fail(NSG_E_NOT_LOADED, "no weights loaded (call nsg_load first)");
     if (n == 0 || n > (size_t)ev->batchMax)
         return fail(NSG_E_INVALID, "batch size %zu outside [1, %d]", n, ev->batchMax);
-    return NSG_OK;
+    // the calling thread may never have called resetGPU for this evaluator (a pipeline's launch
+    // thread, a self-play worker's second executor): every launch below must go to ev's device
+    return bind(ev);
 }
 
 } // namespace
@@ -648,13 +721,14 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
 
     const int prec = ev->prec;
     const int kc = nsg::inputChannelGranule(prec); // input channels are padded to whole chunks (kF16m8: chunk pairs)
-    const int es = nsg::elemSize(prec);
     ev->loaded = false;
-    ev->F = nv.F; ev->blocks = nv.blocks; ev->vc = nv.vc; ev->vh = nv.vh;
-    ev->cpad = roundUp(nv.cin, kc);
-    ev->headsCout = roundUp(nv.vc + nv.pc, 64);
-    ev->fc1K = roundUp(81 * nv.vc, nsg::chunkChannels(nsg::headPrecision(prec)));
-    ev->params = nv.params;
+    auto W = std::make_shared<NetWeights>();
+    W->gpu = ev->gpu; W->prec = prec;
+    W->F = nv.F; W->blocks = nv.blocks; W->vc = nv.vc; W->vh = nv.vh; W->cin = nv.cin;
+    W->cpad = roundUp(nv.cin, kc);
+    W->headsCout = roundUp(nv.vc + nv.pc, 64);
+    W->fc1K = roundUp(81 * nv.vc, nsg::chunkChannels(nsg::headPrecision(prec)));
+    W->params = nv.params;
 
     std::vector<double> scale;
     std::vector<float> bias;
@@ -668,10 +742,8 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
             std::vector<unsigned char> host;
             float accScale = 1.f;
         };
-        ev->conv1.clear(); ev->conv2.clear();
-        ev->conv1.resize(nv.blocks); ev->conv2.resize(nv.blocks);
-        ev->conv1X3.clear(); ev->conv2X3.clear();
-        if (prec == nsg::kF16m8) { ev->conv1X3.resize(nv.blocks); ev->conv2X3.resize(nv.blocks); }
+        W->conv1.resize(nv.blocks); W->conv2.resize(nv.blocks);
+        if (prec == nsg::kF16m8) { W->conv1X3.resize(nv.blocks); W->conv2X3.resize(nv.blocks); }
         std::vector<Job> jobs;
         auto add = [&](const float* w, const float* bn, int cinReal, int kdim, ConvLayer* L, ConvLayer* Lx3) {
             Job j;
@@ -683,10 +755,10 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
                 jobs.push_back(std::move(j));
             }
         };
-        add(nv.stemW, nv.stemBn, nv.cin, ev->cpad, &ev->stem, &ev->stemX3);
+        add(nv.stemW, nv.stemBn, nv.cin, W->cpad, &W->stem, &W->stemX3);
         for (int k = 0; k < nv.blocks; ++k) {
-            add(nv.w1[k], nv.bn1[k], nv.F, nv.F, &ev->conv1[k], prec == nsg::kF16m8 ? &ev->conv1X3[k] : nullptr);
-            add(nv.w2[k], nv.bn2[k], nv.F, nv.F, &ev->conv2[k], prec == nsg::kF16m8 ? &ev->conv2X3[k] : nullptr);
+            add(nv.w1[k], nv.bn1[k], nv.F, nv.F, &W->conv1[k], prec == nsg::kF16m8 ? &W->conv1X3[k] : nullptr);
+            add(nv.w2[k], nv.bn2[k], nv.F, nv.F, &W->conv2[k], prec == nsg::kF16m8 ? &W->conv2X3[k] : nullptr);
         }
         std::atomic<size_t> next{0};
         auto work = [&]() {
@@ -710,54 +782,69 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
     // heads: [value conv (BN folded) | policy conv | zero pad]
     {
         foldBn(nv.valBn, nv.vc, nv.eps, &scale, &bias);
-        std::vector<float> hb(ev->headsCout, 0.f);
+        std::vector<float> hb(W->headsCout, 0.f);
         for (int i = 0; i < nv.vc; ++i) hb[i] = bias[i];
         for (int i = 0; i < nv.pc; ++i) hb[nv.vc + i] = nv.polB[i];
         HeadsCtx c{nv.valW, scale.data(), nv.polW, nv.F, nv.vc, nv.pc};
-        if ((rc = uploadLayer(headsGet, &c, 1, nv.F, nv.F, ev->headsCout, nv.vc + nv.pc, nsg::headPrecision(prec), hb, &ev->heads))) return rc;
+        if ((rc = uploadLayer(headsGet, &c, 1, nv.F, nv.F, W->headsCout, nv.vc + nv.pc, nsg::headPrecision(prec), hb, &W->heads))) return rc;
     }
     {
         std::vector<float> b1(nv.fc1B, nv.fc1B + nv.vh);
         Fc1Ctx c{nv.fc1W, nv.vc};
-        if ((rc = uploadLayer(fc1Get, &c, 1, 81 * nv.vc, ev->fc1K, nv.vh, nv.vh, nsg::headPrecision(prec), b1, &ev->fc1))) return rc;
+        if ((rc = uploadLayer(fc1Get, &c, 1, 81 * nv.vc, W->fc1K, nv.vh, nv.vh, nsg::headPrecision(prec), b1, &W->fc1))) return rc;
     }
-    if ((rc = ev->fc2W.alloc((size_t)2 * nv.vh * 4, false))) return rc;
-    if ((rc = ev->fc2B.alloc(8, false))) return rc;
-    NSG_HIP(hipMemcpy(ev->fc2W.p, nv.fc2W, (size_t)2 * nv.vh * 4, hipMemcpyHostToDevice));
-    NSG_HIP(hipMemcpy(ev->fc2B.p, nv.fc2B, 8, hipMemcpyHostToDevice));
+    if ((rc = W->fc2W.alloc((size_t)2 * nv.vh * 4, false))) return rc;
+    if ((rc = W->fc2B.alloc(8, false))) return rc;
+    NSG_HIP(hipMemcpy(W->fc2W.p, nv.fc2W, (size_t)2 * nv.vh * 4, hipMemcpyHostToDevice));
+    NSG_HIP(hipMemcpy(W->fc2B.p, nv.fc2B, 8, hipMemcpyHostToDevice));
+    return finishLoad(ev, std::move(W));
+}
 
-    // activation buffers: whole workgroups of up to 2 boards
-    const size_t bpad = (size_t)roundUp(ev->batchMax, 2);
-    if ((rc = ev->planes.alloc(bpad * 81 * ev->cpad * es, true))) return rc;
-    for (int i = 0; i < 3; ++i)
-        if ((rc = ev->act[i].alloc(bpad * 81 * nv.F * es, true))) return rc;
-    if ((rc = ev->vfeat.alloc((size_t)ev->batchMax * ev->fc1K * es, true))) return rc;
-    if ((rc = ev->hidden.alloc((size_t)ev->batchMax * nv.vh * 4 * nsg::denseSplits(ev->fc1K, nsg::headPrecision(prec)), true))) return rc;
-    {   // persistent-trunk layer list, same buffer rotation as the per-layer path
-        const int nl = 1 + 2 * nv.blocks;
-        std::vector<unsigned char> host((size_t)nl * nsg::trunkLayerBytes());
-        void* x = ev->act[0].p; void* y = ev->act[1].p; void* z = ev->act[2].p;
-        nsg::fillTrunkLayer(host.data(), 0, ev->planes.p, ev->stem.w.p, (const float*)ev->stem.bias.p,
-                            nullptr, x, ev->cpad, nv.F, 1, ev->stem.accScale);
-        for (int k = 0; k < nv.blocks; ++k) {
-            nsg::fillTrunkLayer(host.data(), 1 + 2 * k, x, ev->conv1[k].w.p, (const float*)ev->conv1[k].bias.p,
-                                nullptr, y, nv.F, nv.F, 1, ev->conv1[k].accScale);
-            nsg::fillTrunkLayer(host.data(), 2 + 2 * k, y, ev->conv2[k].w.p, (const float*)ev->conv2[k].bias.p,
-                                x, z, nv.F, nv.F, 1, ev->conv2[k].accScale,
-                                prec == nsg::kF16m8 && k == nv.blocks - 1);
-            void* t = x; x = z; z = t;
-        }
-        if ((rc = ev->trunkLayers.alloc(host.size(), false))) return rc;
-        NSG_HIP(hipMemcpy(ev->trunkLayers.p, host.data(), host.size(), hipMemcpyHostToDevice));
-        ev->trunkLayerCount = nl;
-        const char* env = getenv("NSG_TRUNK_KERNEL");
-        ev->useTrunkKernel = (env && env[0] == '1');
-    }
+// Loads `ev` with the network `src` already holds, without touching the model file again: the
+// self-play driver's G x T executors (selfplay/main.cc:189-195, mcts/manager.cc:168-179 -- where
+// every executor re-reads and re-builds the model) share ONE upload per device and one peer copy
+// (hipMemcpyPeer over xGMI) per further device.
+int nsg_load_shared(nsg_evaluator* ev, nsg_evaluator* src) {
+    if (!ev || !src) return fail(NSG_E_INVALID, "null argument");
+    if (!src->loaded || !src->W) return fail(NSG_E_NOT_LOADED, "the source evaluator has no weights loaded");
+    if (ev == src) return NSG_OK;
+    if (ev->prec != src->W->prec) return fail(NSG_E_INVALID, "precision differs from the source evaluator's");
+    if (ev->numChannels != src->W->cin)
+        return fail(NSG_E_FORMAT, "network expects %d input planes, evaluator has %d", src->W->cin, ev->numChannels);
+    int rc = bind(ev);
+    if (rc) return rc;
+    ev->loaded = false;
+    if (ev->gpu == src->gpu) return finishLoad(ev, src->W);
+    const NetWeights& S = *src->W;
+    auto W = std::make_shared<NetWeights>();
+    W->gpu = ev->gpu; W->prec = S.prec;
+    W->F = S.F; W->blocks = S.blocks; W->vc = S.vc; W->vh = S.vh; W->cin = S.cin; W->cpad = S.cpad;
+    W->headsCout = S.headsCout; W->fc1K = S.fc1K; W->params = S.params;
+    auto copyBuf = [&](const DevBuf& s, DevBuf* d) -> int {
+        if (!s.p) return NSG_OK;
+        int r = d->alloc(s.bytes, false);
+        if (r) return r;
+        NSG_HIP(hipMemcpyPeer(d->p, ev->gpu, s.p, S.gpu, s.bytes));
+        return NSG_OK;
+    };
+    auto copyLayer = [&](const ConvLayer& s, ConvLayer* d) -> int {
+        d->cin = s.cin; d->accScale = s.accScale;
+        int r = copyBuf(s.w, &d->w);
+        return r ? r : copyBuf(s.bias, &d->bias);
+    };
+    auto copyLayers = [&](const std::vector<ConvLayer>& s, std::vector<ConvLayer>* d) -> int {
+        d->resize(s.size());
+        for (size_t i = 0; i < s.size(); ++i) { int r = copyLayer(s[i], &(*d)[i]); if (r) return r; }
+        return NSG_OK;
+    };
+    if ((rc = copyLayer(S.stem, &W->stem)) || (rc = copyLayer(S.stemX3, &W->stemX3)) ||
+        (rc = copyLayers(S.conv1, &W->conv1)) || (rc = copyLayers(S.conv2, &W->conv2)) ||
+        (rc = copyLayers(S.conv1X3, &W->conv1X3)) || (rc = copyLayers(S.conv2X3, &W->conv2X3)) ||
+        (rc = copyLayer(S.heads, &W->heads)) || (rc = copyLayer(S.fc1, &W->fc1)) ||
+        (rc = copyBuf(S.fc2W, &W->fc2W)) || (rc = copyBuf(S.fc2B, &W->fc2B)))
+        return rc;
     NSG_HIP(hipDeviceSynchronize());
-    ev->calibKey = -1; // a new network: re-measure the layer time for the chain stagger
-    ev->calibPending = false;
-    ev->loaded = true;
-    return NSG_OK;
+    return finishLoad(ev, std::move(W));
 }
 
 int nsg_load(nsg_evaluator* ev, const char* path) {

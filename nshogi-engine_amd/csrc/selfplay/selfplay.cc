@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <new>
 
 namespace nshogi {
 namespace engine {
@@ -20,49 +21,49 @@ using shogi::MoveList;
 
 namespace {
 
-void freeTree(Node* N) {
-    if (!N) return;
-    for (uint16_t I = 0; I < N->NumChildren; ++I) freeTree(N->Edges[I].Child);
-    delete[] N->Edges;
-    delete N;
-}
-
 inline uint64_t mix64(uint64_t X) {
     X ^= X >> 33; X *= 0xff51afd7ed558ccdULL; X ^= X >> 33; X *= 0xc4ceb9fe1a85ec53ULL; X ^= X >> 33;
     return X;
 }
 
-constexpr int kCacheMoves = 112; // positions with more legal moves are not cached
+// Bump arena holding one game's search tree.  The tree is dropped whole whenever the root
+// changes (Tree::updateRoot(State, false), worker.cc:161), so "free" is a rewind: no per-node
+// free list, no recursive walk (role of allocator::FixedAllocator<sizeof(Node)> +
+// SegregatedFreeListAllocator + the GarbageCollector threads, selfplay/main.cc:72-92).
+class Arena {
+ public:
+    void* alloc(std::size_t Bytes) {
+        Bytes = (Bytes + 15) & ~(std::size_t)15;
+        if (Bytes > kChunk) throw std::bad_alloc(); // a node's edges: at most 593 * 16 bytes
+        if (Chunks.empty() || Off + Bytes > kChunk) {
+            if (Cur + 1 < Chunks.size() && !Chunks.empty()) ++Cur;
+            else {
+                Chunks.emplace_back(new unsigned char[kChunk]);
+                Cur = Chunks.size() - 1;
+            }
+            Off = 0;
+        }
+        void* P = Chunks[Cur].get() + Off;
+        Off += Bytes;
+        return P;
+    }
+    void rewind() {
+        Cur = 0;
+        Off = 0;
+    }
+
+ private:
+    static constexpr std::size_t kChunk = 256 * 1024;
+    std::vector<std::unique_ptr<unsigned char[]>> Chunks;
+    std::size_t Cur = 0, Off = 0;
+};
 
 } // namespace
 
-// Evaluation cache: hash -> legal-move logits + values (mcts::EvalCache's role,
-// selfplay/worker.cc:367-378, frame.cc:108-111).  Direct mapped, per engine.
-struct Engine::Cache {
-    struct Entry {
-        uint64_t Hash = 0;
-        uint16_t N = 0;
-        float Win = 0, Draw = 0;
-        float Logit[kCacheMoves];
-    };
-    std::vector<Entry> Entries;
-    explicit Cache(std::size_t Count) : Entries(Count) {}
-    const Entry* load(uint64_t Hash, uint16_t N) const {
-        const Entry& E = Entries[Hash % Entries.size()];
-        return (E.Hash == Hash && E.N == N) ? &E : nullptr;
-    }
-    void store(uint64_t Hash, uint16_t N, const float* Logit, float Win, float Draw) {
-        if (N > kCacheMoves) return;
-        Entry& E = Entries[Hash % Entries.size()];
-        E.Hash = Hash; E.N = N; E.Win = Win; E.Draw = Draw;
-        std::memcpy(E.Logit, Logit, N * sizeof(float));
-    }
-};
-
 class Game {
  public:
-    Game(Engine* E, uint64_t Stream) : Eng(E), StreamId(Stream) { newGame(); }
-    ~Game() { freeTree(Root); }
+    // Slot: this game slot's number among the run's Stride concurrent slots; its k-th game has id Slot + k * Stride
+    Game(Engine* E, uint64_t Slot, uint64_t Stride) : Eng(E), GameId(Slot), Stride(Stride) { newGame(false); }
     Game(const Game&) = delete;
     Game& operator=(const Game&) = delete;
 
@@ -99,19 +100,25 @@ class Game {
             M.V = Leaf->Edges[I].Move16;
             Logits[I] = Policy[shogi::moveIndex(Us, M)];
         }
-        if (Eng->EvalCache) Eng->EvalCache->store(S.hash(), N, Logits, Win, Draw);
+        if (Eng->Cache) Eng->Cache->store(S.hash(), N, Logits, Win, Draw); // frame.cc:108-111
         finishEvaluation(N, Win, Draw);
     }
 
  private:
     enum class Phase { RootPreparation, LeafSelection, LeafTerminalChecking, Evaluation, Backpropagation, Transition, Judging };
 
-    void newGame() {
-        freeTree(Root);
+    Node* newNode(Node* Parent) {
+        Node* N = new (Tree.alloc(sizeof(Node))) Node();
+        N->Parent = Parent;
+        return N;
+    }
+
+    void newGame(bool Next = true) {
+        Tree.rewind();
         Root = nullptr;
         S = shogi::State();
-        Rng.seed(mix64(Eng->Opt.Seed ^ mix64(StreamId * 0x9e3779b97f4a7c15ULL + Serial)));
-        ++Serial;
+        if (Next) GameId += Stride;
+        Rng.seed(mix64(Eng->Opt.Seed ^ mix64(GameId * 0x9e3779b97f4a7c15ULL + 1)));
         // worker.cc:132-150
         std::uniform_int_distribution<int> MaxPly(Eng->Opt.MaxPlyMin, Eng->Opt.MaxPlyMax);
         Config.MaxPly = (uint16_t)MaxPly(Rng);
@@ -129,8 +136,8 @@ class Game {
     float drawValue(Color C) const { return C == shogi::Black ? Config.BlackDrawValue : Config.WhiteDrawValue; }
 
     void prepareRoot() { // worker.cc:159-215
-        freeTree(Root);
-        Root = new Node();
+        Tree.rewind();
+        Root = newNode(nullptr);
         RootPly = S.ply();
         MoveList L;
         S.generateLegalMoves(L);
@@ -278,10 +285,7 @@ class Game {
             if (S.ply() >= Config.MaxPly) break;
             Edge* E = (Eng->Opt.Gumbel && N == Root) ? pickGumbelRootEdge() : pickEdge(N);
             S.doMove(S.moveFrom16(E->Move16));
-            if (!E->Child) {
-                E->Child = new Node();
-                E->Child->Parent = N;
-            }
+            if (!E->Child) E->Child = newNode(N);
             N = E->Child;
         }
         Leaf = N;
@@ -330,13 +334,14 @@ class Game {
         }
         // expand (Node::expand)
         Leaf->NumChildren = (uint16_t)L.size();
-        Leaf->Edges = new Edge[L.size()];
+        Leaf->Edges = static_cast<Edge*>(Tree.alloc(sizeof(Edge) * (std::size_t)L.size()));
         for (int I = 0; I < L.size(); ++I) Leaf->Edges[I] = Edge{L[I].move16(), 0.0f, nullptr};
-        if (Eng->EvalCache) {
-            if (const auto* E = Eng->EvalCache->load(S.hash(), Leaf->NumChildren)) {
-                std::memcpy(Logits, E->Logit, Leaf->NumChildren * sizeof(float));
+        if (Eng->Cache) { // worker.cc:367-378
+            EvalCache::Info& E = Eng->CacheScratch;
+            if (Eng->Cache->load(S.hash(), &E) && E.NumMoves == Leaf->NumChildren) {
+                std::memcpy(Logits, E.Policy, Leaf->NumChildren * sizeof(float));
                 ++Eng->St.CacheHits;
-                finishEvaluation(Leaf->NumChildren, E->Win, E->Draw);
+                finishEvaluation(Leaf->NumChildren, E.WinRate, E.DrawRate);
                 return false;
             }
         }
@@ -435,7 +440,7 @@ class Game {
         S.doMove(M);
         ++GameMoves;
         ++Eng->St.Moves;
-        Eng->Digest += mix64(((uint64_t)StreamId << 40) ^ ((uint64_t)(Serial - 1) << 20) ^ ((uint64_t)GameMoves << 32) ^ M.V);
+        Eng->Digest += mix64(mix64(GameId + 0x51ed270b) ^ ((uint64_t)GameMoves << 32) ^ M.V);
         Ph = Phase::Judging;
     }
 
@@ -445,6 +450,7 @@ class Game {
         else ++Eng->St.GamesDraw;
         Eng->St.MovesOfFinishedGames += GameMoves;
         if (Eng->Teacher) Eng->St.TeacherRecords += Eng->Teacher->saveGame(MoveHistory, FullSearchAt, Config, Winner);
+        if (Eng->Log) Eng->Log->add(GameId, Winner, MoveHistory);
         newGame();
     }
 
@@ -473,8 +479,9 @@ class Game {
     }
 
     Engine* Eng;
-    uint64_t StreamId;
-    uint64_t Serial = 0;
+    uint64_t GameId; // of the game being played: slot + k * Stride
+    uint64_t Stride;
+    Arena Tree;
     shogi::State S;
     shogi::StateConfig Config;
     std::mt19937_64 Rng;
@@ -502,10 +509,12 @@ struct Engine::Group {
     bool InFlight = false;
 };
 
-Engine::Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& O, uint64_t EngineIndex, bool PinMemory)
-    : Opt(O) {
-    if (Opt.EvalCacheEntries) EvalCache = std::make_unique<Cache>(Opt.EvalCacheEntries);
+Engine::Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& O, uint64_t EngineIndex, bool PinMemory,
+               EvalCache* SharedCache)
+    : Opt(O), Cache(SharedCache) {
     infer::Infer* Exec[2] = {Exec0, Exec1};
+    const uint64_t Mine = 2 * (uint64_t)Opt.GamesPerGroup;
+    const uint64_t Stride = Opt.TotalSlots ? Opt.TotalSlots : Mine;
     for (int G = 0; G < 2; ++G) {
         Groups[G] = std::make_unique<Group>();
         Groups[G]->Ev = std::make_unique<evaluate::Evaluator>(EngineIndex * 2 + G, shogi::NumFeaturePlanes,
@@ -513,7 +522,7 @@ Engine::Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& O, uint6
         Groups[G]->Pending.resize(Opt.GamesPerGroup);
         for (int I = 0; I < Opt.GamesPerGroup; ++I)
             Groups[G]->Games.push_back(std::make_unique<Game>(
-                this, (EngineIndex * 2 + (uint64_t)G) * 1000003ULL + (uint64_t)I));
+                this, EngineIndex * Mine + (uint64_t)G * (uint64_t)Opt.GamesPerGroup + (uint64_t)I, Stride));
     }
 }
 
@@ -553,6 +562,9 @@ void Engine::step() {
         apply(*Groups[G]);   // results of this group's previous batch
         collect(*Groups[G]); // host search of this group while the other group's batch computes
     }
+    PubFinished.store(St.finished(), std::memory_order_relaxed);
+    PubEvaluations.store(St.Evaluations, std::memory_order_relaxed);
+    PubMoves.store(St.Moves, std::memory_order_relaxed);
 }
 
 void Engine::drain() {

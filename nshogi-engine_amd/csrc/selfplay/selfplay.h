@@ -11,9 +11,15 @@
 //     leaf batch is on the GPU the thread searches the other group (the reference
 //     brackets a blocking GPU call with serial host loops,
 //     selfplay/evaluationworker.cc:69-117);
-//   * every game has its own RNG seeded from (base seed, game serial) and batch
-//     results are slot-independent, so a run is reproducible bit for bit
-//     (the reference seeds from std::random_device, worker.cc:49-50);
+//   * every game has its own RNG seeded from (base seed, game id): the driver numbers its
+//     concurrent game slots 0..N-1 across all engines and slot s plays the games s, s+N, s+2N, ...
+//     Batch results are slot-independent, so a run is reproducible bit for bit, and -- when the
+//     executor's arithmetic does not depend on the batch size (CPU executors; the HIP evaluator
+//     with a fixed tile plan) -- every game is the same game however the slots are spread over
+//     threads, groups and GPUs (the reference seeds from std::random_device, worker.cc:49-50);
+//   * search trees live in one bump arena per game, rewound when the root changes (the reference
+//     pools nodes and edges in allocator::FixedAllocator / SegregatedFreeListAllocator and frees
+//     them on a garbage-collector thread, selfplay/main.cc:72-92);
 //   * Gumbel mode (worker.cc:428-475 sequential halving, :596-638 transition,
 //     :784-905 sampling / halving schedule) is implemented as in the reference;
 //   * the mate-in-3 search at leaves (worker.cc:349-358) is shogi::State::findMate(3) and the
@@ -30,9 +36,11 @@
 #include "../shogi/dfpn.h"
 #include "../shogi/features.h"
 #include "../shogi/shogi.h"
+#include "evalcache.h"
 
 #include <nshogi_engine_amd/infer/infer.h>
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <random>
@@ -52,7 +60,7 @@ struct Options {
     int MaxPlyMin = 160 + 64;    // worker.cc:135-136
     int MaxPlyMax = 512 + 128;
     bool RandomDrawValue = true; // worker.cc:142-150
-    std::size_t EvalCacheEntries = 1 << 15; // per engine; 0 disables
+    uint64_t TotalSlots = 0;     // concurrent games of the whole run (all engines); 0 = this engine's own
     uint64_t DfpnNodes = 100000; // node budget of the df-pn mate solver run after every move (worker.cc:516); 0 = off
     bool MateSearch = true;      // mate-in-3 search by checks at every non-root leaf (worker.cc:349-358)
 };
@@ -90,12 +98,16 @@ struct Node {
 
 class Game; // one Frame
 class TeacherWriter; // teacher.h
+class GameLog;       // teacher.h: one line per finished game
 
 // One engine = one search thread's worth of games + its two executors.
 class Engine {
  public:
     // Exec[0], Exec[1]: one executor per group (not owned).  BatchMax >= GamesPerGroup.
-    Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& Opt, uint64_t EngineIndex, bool PinMemory);
+    // Cache: the GPU shard's evaluation cache (shared with the shard's other engines, not owned;
+    // nullptr = no cache).  Engine e owns the game slots [e * 2 * GamesPerGroup, (e+1) * 2 * GamesPerGroup).
+    Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& Opt, uint64_t EngineIndex, bool PinMemory,
+           EvalCache* Cache);
     ~Engine();
 
     // Runs until `Stop` becomes true or `MaxFinishedGames` games have finished (0 = no limit).
@@ -106,9 +118,17 @@ class Engine {
 
     // Finished games are written to W (shared, not owned; nullptr = off).  Set before run().
     void setTeacherWriter(TeacherWriter* W) { Teacher = W; }
+    void setGameLog(GameLog* L) { Log = L; }
+
+    // Progress counters another thread may read while run() is going (the driver's rate timeline)
+    uint64_t publishedFinished() const { return PubFinished.load(std::memory_order_relaxed); }
+    uint64_t publishedEvaluations() const { return PubEvaluations.load(std::memory_order_relaxed); }
+    uint64_t publishedMoves() const { return PubMoves.load(std::memory_order_relaxed); }
 
     const Stats& stats() const { return St; }
-    // order-independent digest of every move played so far (reproducibility checks)
+    // order-independent digest of every move played so far (reproducibility checks): a wrapping sum
+    // over (game id, ply, move), so engines' digests add up to the same total however the game slots
+    // are spread over them
     uint64_t moveDigest() const { return Digest; }
 
  private:
@@ -119,11 +139,13 @@ class Engine {
     Options Opt;
     Stats St;
     TeacherWriter* Teacher = nullptr;
+    GameLog* Log = nullptr;
     shogi::DfpnSolver Solver;
     uint64_t Digest = 0;
+    std::atomic<uint64_t> PubFinished{0}, PubEvaluations{0}, PubMoves{0};
     std::unique_ptr<Group> Groups[2];
-    struct Cache;
-    std::unique_ptr<Cache> EvalCache;
+    EvalCache* Cache = nullptr;
+    EvalCache::Info CacheScratch;
     friend class Game;
 };
 

@@ -55,6 +55,31 @@ std::size_t TeacherWriter::saveGame(const std::vector<uint32_t>& Moves, const st
     return Buf.size();
 }
 
+GameLog::GameLog(const std::string& Path) {
+    Out = std::fopen(Path.c_str(), "w");
+    if (!Out) throw std::runtime_error("could not open the game log: " + Path);
+}
+
+GameLog::~GameLog() {
+    if (Out) std::fclose(Out);
+}
+
+void GameLog::add(uint64_t GameId, shogi::Color Winner, const std::vector<uint32_t>& Moves) {
+    uint64_t Digest = 0xcbf29ce484222325ULL; // FNV-1a over the move words
+    std::string Line;
+    for (uint32_t V : Moves) {
+        Digest = (Digest ^ V) * 0x100000001b3ULL;
+        shogi::Move M;
+        M.V = V;
+        Line += ' ';
+        Line += shogi::moveToUsi(M);
+    }
+    std::lock_guard<std::mutex> Lock(Mutex);
+    std::fprintf(Out, "%llu %d %zu %llu%s\n", (unsigned long long)GameId, (int)Winner, Moves.size(),
+                 (unsigned long long)Digest, Line.c_str());
+    std::fflush(Out);
+}
+
 } // namespace selfplay
 } // namespace engine
 } // namespace nshogi

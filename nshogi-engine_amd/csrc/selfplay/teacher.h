@@ -65,6 +65,22 @@ class TeacherWriter {
     uint64_t Records = 0;
 };
 
+// One text line per finished game: "<game id> <winner 0|1|2> <plies> <move digest> <usi moves...>".
+// The game id is global to the run (slot + k * slots), so two runs that spread the same slots
+// differently over threads, groups and GPUs can be compared game by game.
+class GameLog {
+ public:
+    explicit GameLog(const std::string& Path);
+    ~GameLog();
+    GameLog(const GameLog&) = delete;
+    GameLog& operator=(const GameLog&) = delete;
+    void add(uint64_t GameId, shogi::Color Winner, const std::vector<uint32_t>& Moves);
+
+ private:
+    std::FILE* Out = nullptr;
+    std::mutex Mutex;
+};
+
 } // namespace selfplay
 } // namespace engine
 } // namespace nshogi

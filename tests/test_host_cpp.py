@@ -105,3 +105,15 @@ def test_batch_pipeline_hip_bit_identical(nsg, tmp_path, cfg):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "missing 0 dup 0 wrong 0" in r.stdout
+
+
+def test_evaluator_numa_placement_and_pool_size_check():
+    """Evaluator(NumaPlacement=true): thread bound to node ThreadId % nodes, buffers first-touched
+    there (evaluator.cc:46-76 restated on /sys + sched_setaffinity); one-node machines are left alone.
+    BatchPipeline refuses a buffer pool smaller than Depth + 1 instead of deadlocking in openNext."""
+    _build()
+    r = subprocess.run([os.path.join(HOST, "pipeline_test"), "numa"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "numa ok" in r.stdout, r.stdout + r.stderr
+    assert int(r.stdout.split()[1]) >= 1
+    r = subprocess.run([os.path.join(HOST, "pipeline_test"), "badpool"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "refused" in r.stdout, r.stdout + r.stderr

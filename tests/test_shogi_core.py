@@ -175,10 +175,78 @@ def test_selfplay_gumbel_mode_cpu():
     assert a["playouts_per_sec"] > 0 and a["moves"] > 0
 
 
+def _game_log(path):
+    games = {}
+    for ln in open(path):
+        gid, rest = ln.split(" ", 1)
+        games[int(gid)] = rest
+    return games
+
+
+def test_selfplay_games_do_not_depend_on_grouping(tmp_path):
+    """Game slot s plays the games s, s+N, s+2N, ... each from its own RNG stream, so with an
+    executor whose outputs do not depend on batch composition (infer::Zero here) every game is the
+    same game however the N slots are spread: 1 thread x 2 groups x 6, 2 threads x 2 x 3 sharing one
+    evaluation cache, or two GPU shards (--num-gpus 2; the CPU executors stand in for the devices)
+    x 1 thread x 2 x 3."""
+    base = ["--executor", "zero", "--playouts", "40", "--seed", "3", "--dfpn-nodes", "2000", "--max-games", "10"]
+    logs = []
+    for i, shape in enumerate((["--threads", "1", "--games-per-group", "6"],
+                               ["--threads", "2", "--games-per-group", "3", "--share-evaluation-cache", "1"],
+                               ["--num-gpus", "2", "--threads", "1", "--games-per-group", "3"])):
+        path = tmp_path / f"g{i}.log"
+        out = json.loads(run("selfplay", *base, *shape, "--game-log", path))
+        assert out["concurrent_games"] == 12 and out["games_finished"] >= 10
+        logs.append(_game_log(path))
+    assert json.loads(run("selfplay", *base, "--num-gpus", "2", "--threads", "1", "--games-per-group", "3"))["num_gpus"] == 2
+    common = set(logs[0]) & set(logs[1]) & set(logs[2])
+    assert len(common) >= 6
+    for gid in common:
+        assert logs[0][gid] == logs[1][gid] == logs[2][gid], gid
+    # the per-GPU shards both worked
+    out = json.loads(run("selfplay", *base, "--num-gpus", "2", "--threads", "2", "--games-per-group", "2"))
+    assert len(out["evals_per_sec_by_gpu"]) == 2 and all(x > 0 for x in out["evals_per_sec_by_gpu"])
+
+
+def test_selfplay_windowed_rate_and_cache_options():
+    out = json.loads(run("selfplay", "--executor", "random", "--threads", "1", "--games-per-group", "4", "--playouts", "16",
+                         "--seconds", "3", "--seed", "2", "--dfpn-nodes", "0", "--mate-search", "0",
+                         "--evaluation-cache-memory-size", "16"))
+    assert out["games_finished"] > 0 and out["games_per_sec_window"] > 0 and 1.0 < out["window_seconds"] < 2.5
+    assert out["evaluation_cache_mb_per_gpu"] == 16 and 0 < out["cache_hit_ratio"] < 1
+    off = json.loads(run("selfplay", "--executor", "random", "--threads", "1", "--games-per-group", "4", "--playouts", "16",
+                         "--max-games", "2", "--seed", "2", "--dfpn-nodes", "0", "--evaluation-cache-memory-size", "0"))
+    assert off["cache_hit_ratio"] == 0
+
+
+@pytest.mark.gpu
+def test_selfplay_hip_games_do_not_depend_on_grouping(nsg, tmp_path, monkeypatch):
+    """The same on the HIP evaluator, in the arithmetic that does not depend on the batch size: the
+    f32 path with one fixed tile plan (NSG_CONV_NB=1, NSG_CONV_NFRAG=4 -- by default the plan, and
+    with it the f32 summation order, follows the batch size).  Cache hits return what a fresh
+    evaluation would, so the evaluation cache does not disturb this either."""
+    monkeypatch.setenv("NSG_CONV_NB", "1")
+    monkeypatch.setenv("NSG_CONV_NFRAG", "4")
+    path = tmp_path / "net.nsgw"
+    nsg.weights.save(str(path), nsg.weights.make_random(2, 64, seed=3, bn="random"))
+    base = ["--executor", "hip", "--weights", str(path), "--precision", "0", "--playouts", "24", "--seed", "9",
+            "--max-games", "8", "--dfpn-nodes", "2000"]
+    logs = []
+    for i, shape in enumerate((["--threads", "1", "--games-per-group", "6"], ["--threads", "2", "--games-per-group", "3"])):
+        lp = tmp_path / f"h{i}.log"
+        json.loads(run("selfplay", *base, *shape, "--game-log", lp))
+        logs.append(_game_log(lp))
+    common = set(logs[0]) & set(logs[1])
+    assert len(common) >= 4
+    for gid in common:
+        assert logs[0][gid] == logs[1][gid], gid
+
+
 @pytest.mark.gpu
 def test_selfplay_hip_reproducible(nsg, tmp_path):
-    """Self-play on the HIP evaluator: move selection is bit-identical under a fixed
-    seed (north_star) -- across runs and regardless of how games are grouped into batches."""
+    """Self-play on the HIP evaluator: move selection is bit-identical under a fixed seed
+    (north_star) from run to run of one configuration (independence from the grouping of the game
+    slots: test_selfplay_hip_games_do_not_depend_on_grouping)."""
     path = tmp_path / "net.nsgw"
     nsg.weights.save(str(path), nsg.weights.make_random(2, 64, seed=3, bn="random"))
     base = ["--executor", "hip", "--weights", str(path), "--playouts", "24", "--max-games", "4", "--seed", "9",
