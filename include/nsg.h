@@ -57,6 +57,13 @@ extern "C" {
  * ~2e-4 from the CPU fp32 executor on the 20x256 net (F16X3: 5e-6).  Trunk
  * convolutions only; the heads and the value MLP run as F16X3. */
 #define NSG_PRECISION_F16M8 4
+/* F16M8 with the correction operands in e2m3 (fp6) under one E8M0 scale per 32
+ * input channels, applied by the MX instruction itself: with both operands in
+ * fp6 it retires K = 128 in the cycles of one f16 MFMA, 1.5 MFMA units per MAC,
+ * and block scales instead of F16M8's fixed ones mean no clamp window -- the
+ * exponent follows the data.  Same accuracy class as F16M8 (~1e-4 on the
+ * 20x256 net); trunk convolutions only, heads and value MLP run as F16X3. */
+#define NSG_PRECISION_F16M6 5
 
 typedef struct nsg_evaluator nsg_evaluator;
 

@@ -15,11 +15,12 @@ PRECISION_FP16 = 1
 PRECISION_BF16 = 2
 PRECISION_F16X3 = 3
 PRECISION_F16M8 = 4
+PRECISION_F16M6 = 5
 MOVE_INDEX_MAX = 2187
 NUM_SQUARES = 81
 BITBOARD_BYTES = 16
 
-_PREC_NAMES = {"fp32": 0, "f32": 0, "fp16": 1, "f16": 1, "bf16": 2, "f16x3": 3, "f16m8": 4}
+_PREC_NAMES = {"fp32": 0, "f32": 0, "fp16": 1, "f16": 1, "bf16": 2, "f16x3": 3, "f16m8": 4, "f16m6": 5}
 
 
 class NsgError(RuntimeError):

@@ -200,6 +200,82 @@ __global__ __launch_bounds__(kThreads) void extractAct(
     }
 }
 
+// ---- kF16m6 trunk input: per (square, 32-channel chunk) one 128-byte row
+// [32 x f16 hi][e2m3(hi) block][e2m3(lo) block, channels 16..31, 0..15], each block 24 B of codes +
+// its E8M0 exponent (kernels.h).  One thread per (square, chunk); values are plane bits and four
+// scalar planes, so a software encoder is plenty here (the trunk's epilogue uses the packed
+// conversion instructions).
+__device__ __forceinline__ unsigned encodeE2m3(float q) { // q already divided by the block scale; RNE, saturating
+    const unsigned sign = (__float_as_uint(q) >> 31) << 5;
+    const float a = fabsf(q);
+    if (!(a < 7.5f)) return sign | 0x1fu;
+    const int ex = a >= 4.f ? 2 : (a >= 2.f ? 1 : 0);
+    const float step = ex == 2 ? 0.5f : (ex == 1 ? 0.25f : 0.125f);
+    const float r = rintf(a / step) * step;
+    if (r >= 7.5f) return sign | 0x1fu;
+    if (r < 1.f) return sign | (unsigned)(r * 8.f);
+    const int e2 = r >= 4.f ? 2 : (r >= 2.f ? 1 : 0);
+    const float st2 = e2 == 2 ? 0.5f : (e2 == 1 ? 0.25f : 0.125f);
+    return sign | (unsigned)(((e2 + 1) << 3) | (((int)(r / st2) - 8) & 7));
+}
+// 32 values (slot order) -> 24 bytes of codes + exponent byte at [24]
+__device__ __forceinline__ void packE2m3BlockDev(const float* v, unsigned char* out) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(v[j]));
+    const unsigned ef = __float_as_uint(m) >> 23;          // biased exponent of the maximum (m >= 0)
+    const unsigned e8 = m > 0.f ? (ef > 3u ? ef - 2u : 1u) : 0u;
+    const float inv = __uint_as_float((254u - e8) << 23);  // 2^(127 - e8)
+    uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const unsigned code = e8 ? encodeE2m3(v[j] * inv) : 0u;
+        const int bit = 6 * j;
+        w[bit / 32] |= code << (bit % 32);
+        if (bit % 32 > 26) w[bit / 32 + 1] |= code >> (32 - bit % 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) reinterpret_cast<uint32_t*>(out)[i] = w[i];
+    reinterpret_cast<uint32_t*>(out)[6] = e8;
+    reinterpret_cast<uint32_t*>(out)[7] = 0u;
+}
+
+__global__ __launch_bounds__(kThreads) void extractActM6(
+    unsigned char* __restrict__ dst, const uint4* __restrict__ src, int channels, int cpad) {
+    extern __shared__ __attribute__((aligned(16))) uint4 sBoard[];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < channels; c += kThreads) sBoard[c] = src[(size_t)b * channels + c];
+    __syncthreads();
+    const int chunks = cpad / 32;
+    for (int it = threadIdx.x; it < 81 * chunks; it += kThreads) {
+        const int sq = it / chunks, kc = it - sq * chunks;
+        float hi[32], lo[32];
+        uint32_t hbits[16];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int c = kc * 32 + i;
+            float v = 0.f;
+            if (c < channels) {
+                const uint4 bb = sBoard[c];
+                const uint64_t l64 = ((uint64_t)bb.y << 32) | bb.x;
+                const uint64_t h64 = ((uint64_t)bb.w << 32) | bb.z;
+                v = fminf(fmaxf(__uint_as_float(selectBit(l64, h64, sq)), -65000.f), 65000.f);
+            }
+            const _Float16 h = (_Float16)v;
+            hi[i] = (float)h;
+            lo[(i + 16) & 31] = v - (float)h; // lo block slots: channels 16..31, then 0..15
+            const uint32_t hb = __builtin_bit_cast(uint16_t, h);
+            if (i & 1) hbits[i >> 1] |= hb << 16; else hbits[i >> 1] = hb;
+        }
+        unsigned char* row = dst + ((size_t)b * 81 + sq) * cpad * 4 + (size_t)kc * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            reinterpret_cast<uint4*>(row)[i] = make_uint4(hbits[4 * i], hbits[4 * i + 1], hbits[4 * i + 2], hbits[4 * i + 3]);
+        packE2m3BlockDev(hi, row + 64);
+        packE2m3BlockDev(lo, row + 96);
+    }
+}
+
 // activations [b][sq][c] T -> f32 [b][c][sq]   (debug read-back only)
 template <int PREC>
 __global__ void actToNCHW(const void* __restrict__ xv, float* __restrict__ dst, int c) {
@@ -263,6 +339,10 @@ hipError_t launchExtractBitsAct(void* dst, const uint64_t* src, int batch,
     } else if (prec == kF16m8) {
         hipLaunchKernelGGL(extractAct<kF16m8>, dim3(batch), dim3(kThreads), smem,
                            stream, dst, (const uint4*)src, channels, cpad);
+    } else if (prec == kF16m6) {
+        if (cpad % 32 != 0) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(extractActM6, dim3(batch), dim3(kThreads), smem,
+                           stream, (unsigned char*)dst, (const uint4*)src, channels, cpad);
     } else {
         hipLaunchKernelGGL(extractAct<kBf16>, dim3(batch), dim3(kThreads), smem,
                            stream, dst, (const uint4*)src, channels, cpad);

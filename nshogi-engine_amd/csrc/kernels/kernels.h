@@ -26,16 +26,29 @@ namespace nsg {
 // of 3 MFMA units per MAC.  Activations: 128-byte chunks of 32 channels,
 // [32 x f16 hi][32 x e4m3(hi)][32 x e4m3(lo * 2^12)].  The 1x1 heads and the value MLP of
 // a kF16m8 evaluator run as kF16x3 (the last trunk layer writes the kF16x3 layout).
-enum Precision { kFp32 = 0, kFp16 = 1, kBf16 = 2, kF16x3 = 3, kF16m8 = 4 };
+//
+// kF16m6: kF16m8 with the correction operands in e2m3 (fp6) and ONE E8M0 scale per 32 input
+// channels -- per (row, chunk) for the activation copies, per (output channel, tap, chunk) for
+// the weight copies -- which the MX instruction applies itself.  With both operands in fp6 it
+// retires its K = 128 in the cycles of ONE f16 MFMA (half the e4m3 form:
+// profiles/r02/a_fp6_probe.txt): 1.5 MFMA units per MAC.  No fixed scales, hence no clamp
+// window: the block exponent follows the data.  Activations: 128-byte chunks of 32 channels,
+// [32 x f16 hi][24 B: e2m3(hi), channel order 0..31][1 B E8M0][7 B pad]
+//              [24 B: e2m3(lo), channel order 16..31, 0..15][1 B E8M0][7 B pad]
+// (the lo block is rotated because the lane that encodes it holds channels 16..31 itself and
+// receives 0..15 from its neighbour; the weight copy that multiplies it is packed in the same order).
+enum Precision { kFp32 = 0, kFp16 = 1, kBf16 = 2, kF16x3 = 3, kF16m8 = 4, kF16m6 = 5 };
+// the two split-precision trunk formats that run their correction terms on the MX instruction
+constexpr bool isMx(int prec) { return prec == kF16m8 || prec == kF16m6; }
 constexpr int kM8LoShift = 12;   // stored lo byte = e4m3(lo * 2^12)
 constexpr int kM8WLoShift = 10;  // weight record  = e4m3(w_lo * 2^10)
 constexpr int kM8WHiShift = -2;  // weight record  = e4m3(w_hi * 2^-2); both products carry 2^-10
 constexpr int kM8ScaleByte = 127 - 10; // E8M0 block scale of the weight operand
 
 // Bytes one activation channel occupies (a kF16x3 pair is 2 + 2 bytes, kF16m8 2 + 1 + 1).
-inline int elemSize(int prec) { return (prec == kFp32 || prec == kF16x3 || prec == kF16m8) ? 4 : 2; }
+inline int elemSize(int prec) { return (prec == kFp32 || prec == kF16x3 || isMx(prec)) ? 4 : 2; }
 // Precision of the 1x1 heads / value MLP of an evaluator whose trunk runs at `prec`.
-inline int headPrecision(int prec) { return prec == kF16m8 ? (int)kF16x3 : prec; }
+inline int headPrecision(int prec) { return isMx(prec) ? (int)kF16x3 : prec; }
 // Channels per 128-byte K chunk of the trunk convolution.
 inline int chunkChannels(int prec) { return 128 / elemSize(prec); }
 // MFMA K-slabs per (chunk, tap): two halves of the chunk, or for kF16x3 the three
@@ -48,10 +61,10 @@ inline int recordsPerTap(int) { return 2; }
 // tap one f16 record for each chunk (w_hi) plus two records holding the 32 fp8 bytes per lane of
 // the MX operand (k-group g: chunk g>>1, g&1 ? e4m3(w_hi) : e4m3(w_lo)) -- 4 per tap and pair.
 inline int recordsPerChunk(int taps, int prec) {
-    return prec == kF16m8 ? 2 * taps : taps * recordsPerTap(prec);
+    return isMx(prec) ? 2 * taps : taps * recordsPerTap(prec);
 }
 // Input channels are padded to whole chunks; kF16m8 to whole chunk pairs.
-inline int inputChannelGranule(int prec) { return prec == kF16m8 ? 2 * chunkChannels(prec) : chunkChannels(prec); }
+inline int inputChannelGranule(int prec) { return isMx(prec) ? 2 * chunkChannels(prec) : chunkChannels(prec); }
 
 // ---- feature-plane expansion (reference K1/K2, src/cuda/extractbit.cu) ----
 hipError_t launchExtractBitsNCHW(float* dst, const uint64_t* src, int batch,

@@ -210,7 +210,7 @@ template <int MODE, int SIZE, int NWAVES, int NFRAG = 4, int PREC = 0>
 constexpr int minWavesPerSimd() {
     // (two boards with 2 fragments per wave would spill at 256 registers: measured slower;
     // the kF16m8 loop needs ~450 registers at any tile size)
-    return (MODE == kConv && SIZE == 1 && (NWAVES >= 3 || NFRAG <= 2) && PREC != kF16m8) ? 2 : 1;
+    return (MODE == kConv && SIZE == 1 && (NWAVES >= 3 || NFRAG <= 2) && !isMx(PREC)) ? 2 : 1;
 }
 
 // kF16m8 slab sequence of one PAIR of channel chunks (A, B): for every tap t the triple
@@ -246,18 +246,19 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 // 256 channels), so the loop has no staging and no barriers.
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1>
 __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
-    using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? (KS > 1 ? 8 : 4) : 2)>;
-    static_assert(KS == 1 || (PREC == kF16m8 && MODE == kConv && SIZE == 1 && MS == 1 && NWAVES % KS == 0),
+    using G = Geom<MODE, SIZE, NWAVES, (isMx(PREC) ? (KS > 1 ? 8 : 4) : 2)>;
+    static_assert(KS == 1 || (isMx(PREC) && MODE == kConv && SIZE == 1 && MS == 1 && NWAVES % KS == 0),
                   "K split: kF16m8 one-board conv tiles");
     const bool hasRes = (RES == 1) || (RES == 2 && A.res != nullptr);
     NSG_STAMP(0);
-    constexpr bool kM8 = (PREC == kF16m8);
+    constexpr bool kM8 = isMx(PREC);          // f16 main term + MX correction terms (the kF16m8 main loop)
+    constexpr bool kM6 = (PREC == kF16m6);    // ... with e2m3 operands and per-block E8M0 scales
     constexpr int ES = (PREC == kFp32 || PREC == kF16x3 || kM8) ? 4 : 2;
     constexpr bool kSplit = (PREC == kF16x3);
     static_assert(!kM8 || (MODE == kConv && NFRAG == 4), "kF16m8: full trunk-conv tiles only");
     static_assert(NFRAG == 1 || NFRAG == 2 || NFRAG == 4, "fragments per wave");
     static_assert(MS == 1 || (MODE == kConv && SIZE == 1 && G::kMF % MS == 0 && NWAVES % MS == 0 &&
-                              (NFRAG < 4 || PREC == kF16m8)),
+                              (NFRAG < 4 || isMx(PREC))),
                   "row split: one-board conv tiles (small tiles, or kF16m8 full-channel tiles)");
     constexpr int kMFw = G::kMF / MS; // row fragments this wave computes
 
@@ -518,8 +519,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                         for (int j = 0; j < NFRAG; ++j) {
                             const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[Q::tap(s) & 1][j][0]),
                                                                      __builtin_bit_cast(i32x4_t, w8[Q::tap(s) & 1][j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
-                            acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 0, 0, 0,
-                                                                                        kM8ScaleByte, 0, 127);
+                            if constexpr (kM6) // e2m3 x e2m3; dword 6 of either operand block carries its E8M0 exponent in byte 0
+                                acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 2, 2, 0, wa[6], 0, xb[6]);
+                            else
+                                acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 0, 0, 0,
+                                                                                            kM8ScaleByte, 0, 127);
                         }
                     } else {
 #pragma unroll
@@ -903,7 +907,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         const size_t sliceOff = (size_t)waveGroup * kRowB;
         // byte offset, inside the row slice, of this lane's k-th 16-byte piece
         auto pieceOff = [&](int k) -> int {
-            if constexpr (kSplit) return (g >> 1) * 128 + (g & 1) * 32 + (k & 1) * 16 + (k >> 1) * 64;
+            // kF16m6: pieces 0,1 = f16 hi of this lane's 16 channels; 2,3 = the 32-byte e2m3 block this lane
+            // encodes (even lane group: the chunk's hi block at +64, odd: its lo block at +96) -- the kF16x3 map
+            if constexpr (kSplit || kM6) return (g >> 1) * 128 + (g & 1) * 32 + (k & 1) * 16 + (k >> 1) * 64;
             else if constexpr (kM8) // pieces 0,1: f16 hi; 2: e4m3(hi); 3: e4m3(lo * 2^12) of this lane's 16 channels
                 return (g >> 1) * 128 + (k < 2 ? (g & 1) * 32 + k * 16 : 64 + (k - 2) * 32 + (g & 1) * 16);
             else return g * (kRowB / 4) + k * 16;
@@ -981,8 +987,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     *reinterpret_cast<u32x4*>(ebuf + (f % kRegions) * kFragBytes + r * kRowS + lpc * 16) = t;
                 }
 #pragma unroll
-                for (int k = 0; k < kNP; ++k)
-                    rpp[f & 1][k] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + li * kRowS + pieceOff(k));
+                for (int k = 0; k < kNP; ++k) {
+                    // (kF16m6: both lanes of a chunk read the chunk's whole lo block, pieces 2 and 3)
+                    const int po = (kM6 && k >= 2) ? (g >> 1) * 128 + 96 + (k - 2) * 16 : pieceOff(k);
+                    rpp[f & 1][k] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + li * kRowS + po);
+                }
             }
             if (i >= 0 && i < kMFe) { // ---- X(i)
                 const int f = i;
@@ -1009,6 +1018,23 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                                 v[k * 8 + 2 * i + 1] += f16BitsToF32((uint16_t)(rp[k][i] >> 16)) +
                                                         f16BitsToF32((uint16_t)(rp[2 + k][i] >> 16));
                             }
+                    } else if constexpr (kM6) {
+                        // lo block -> 32 f16 (v_cvt_scalef32_pk32_f16_fp6 multiplies by the block scale); slots
+                        // 0..15 are the odd lane group's channels, 16..31 the even one's
+                        typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+                        typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+                        const u32x6 blk = {rp[2][0], rp[2][1], rp[2][2], rp[2][3], rp[3][0], rp[3][1]};
+                        const float sc = __uint_as_float((rp[3][2] & 0xffu) << 23);
+                        u32x16 lh;
+                        asm volatile("v_cvt_scalef32_pk32_f16_fp6 %0, %1, %2" : "=&v"(lh) : "v"(blk), "v"(sc));
+                        const bool odd = (g & 1) != 0;
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) { // dword d of my half = channels 2d, 2d+1
+                            const uint32_t l2 = odd ? lh[d] : lh[8 + d];
+                            const uint32_t h2 = rp[d >> 2][d & 3];
+                            v[2 * d] += f16BitsToF32((uint16_t)(h2 & 0xffffu)) + f16BitsToF32((uint16_t)(l2 & 0xffffu));
+                            v[2 * d + 1] += f16BitsToF32((uint16_t)(h2 >> 16)) + f16BitsToF32((uint16_t)(l2 >> 16));
+                        }
                     } else if constexpr (kM8) {
                         constexpr float kLoInv = 1.0f / (float)(1 << kM8LoShift);
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1065,6 +1091,49 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                             op[k][i] = h2;
                             op[2 + k][i] = l2;
                         }
+                    } else if constexpr (kM6) {
+                        // f16 hi pairs, f16 copies of lo; block maxima -> E8M0 exponents (OCP MX rule: exponent
+                        // of the maximum minus 2); the lane groups (g, g^1) of a chunk swap what the other needs
+                        // -- even lanes encode the hi block [own 0..15, neighbour's 16..31], odd lanes the lo block
+                        // [own 16..31, neighbour's 0..15] -- one packed conversion each.
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                        typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+                        typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+                        uint32_t hp[8], lp[8];
+                        float mh = 0.f, ml = 0.f;
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) {
+                            const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * d], floorV, 65000.f),
+                                             __builtin_amdgcn_fmed3f(v[2 * d + 1], floorV, 65000.f)};
+                            const f16x2 h = __builtin_convertvector(x, f16x2);
+                            const f32x2 hx = __builtin_convertvector(h, f32x2);
+                            const f32x2 lx = x - hx;
+                            hp[d] = __builtin_bit_cast(uint32_t, h);
+                            lp[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lx, f16x2));
+                            mh = fmaxf(mh, fmaxf(fabsf(hx[0]), fabsf(hx[1])));
+                            ml = fmaxf(ml, fmaxf(fabsf(lx[0]), fabsf(lx[1])));
+                        }
+                        op[0] = u32x4{hp[0], hp[1], hp[2], hp[3]};
+                        op[1] = u32x4{hp[4], hp[5], hp[6], hp[7]};
+                        const bool odd = (g & 1) != 0;
+                        // 0x401F: ds_swizzle bit mode, lane ^ 16 (profiles/r02/a_fp6_cvt_probe2.txt)
+                        mh = fmaxf(mh, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(mh), 0x401F)));
+                        ml = fmaxf(ml, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ml), 0x401F)));
+                        const uint32_t ef = __float_as_uint(odd ? ml : mh) >> 23; // biased exponent of my block's maximum
+                        const uint32_t e8 = ef > 3u ? ef - 2u : 1u;
+                        u32x16 src;
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) {
+                            const uint32_t give = odd ? hp[d] : lp[d];  // what the neighbour's block needs from me
+                            src[d] = odd ? lp[d] : hp[d];               // my block, own half first
+                            src[8 + d] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)give, 0x401F);
+                        }
+                        u32x6 blk;
+                        const float sc = __uint_as_float(e8 << 23);
+                        asm volatile("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(blk) : "v"(src), "v"(sc));
+                        op[2] = u32x4{blk[0], blk[1], blk[2], blk[3]};
+                        op[3] = u32x4{blk[4], blk[5], e8, 0u};
                     } else {
                         // two values per instruction where the ISA has a packed form (v_cvt_pk_f16_f32,
                         // v_pk_add_f32, v_pk_mul_f32); v_med3 needs no NaN-quieting of its inputs
@@ -1204,7 +1273,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
 
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int MS = 1, int KS = 1>
 hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
-    using G = Geom<MODE, SIZE, NWAVES, (PREC == kF16m8 ? (KS > 1 ? 8 : 4) : 2)>;
+    using G = Geom<MODE, SIZE, NWAVES, (isMx(PREC) ? (KS > 1 ? 8 : 4) : 2)>;
     const int gy = a.cout / (NWAVES / (MS * KS) * NFRAG * 16);
     if (gy < 1 || gy * (NWAVES / (MS * KS)) * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
     if (KS > 1) { // every chunk tile resident: at most eight, and whole pairs for every K part
@@ -1240,7 +1309,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
 
 template <int PREC, int SIZE, int NFRAG, int NWAVES>
 hipError_t launchTrunkOne(const Args* layers, int nLayers, int gridX, hipStream_t stream) {
-    using G = Geom<kConv, SIZE, NWAVES, (PREC == kF16m8 ? 4 : 2)>;
+    using G = Geom<kConv, SIZE, NWAVES, (isMx(PREC) ? 4 : 2)>;
     auto k = trunkKernel<PREC, SIZE, NFRAG, NWAVES>;
     hipError_t err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc);
     if (err != hipSuccess) return err;
@@ -1297,6 +1366,8 @@ hipError_t launchDenseBf16(const Args& a, hipStream_t s);
 hipError_t launchConvF16x3(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkF16m8(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchConvF16m6(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchTrunkF16m6(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkFp32(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkFp16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkBf16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);

@@ -1,0 +1,39 @@
+// mfma_tile_f16m6.hip -- kF16m6 (f16 main term + e2m3 MX correction terms with per-block E8M0 scales) instantiations of
+// the trunk convolution: full tiles only (4 fragments per wave).
+#include "mfma_tile.h"
+
+namespace nsg {
+namespace tile {
+
+hipError_t launchConvF16m6(const Args& a, int batch, const ConvPlan& p, hipStream_t s) {
+    const int gx = (batch + p.nb - 1) / p.nb;
+    if (p.nfrag != 4) return hipErrorInvalidValue;
+    // mid batches: one board per workgroup, two wave groups on three row fragments each
+    // ... or, where all the board's chunk tiles fit in LDS at once, two K halves on all six row fragments
+    if (p.ksplit == 4 && p.nb == 1 && p.nwaves == 4) {
+        // small batches: four K quarters on one 64-channel group (four workgroups per board); a layer with
+        // fewer than four chunk pairs (the stem) runs the two-halves kernel
+        if ((a.kdim / 32) % 8 == 0) return launchOne<kF16m6, kConv, 1, 4, 4, 1, 4>(a, gx, s);
+        return launchOne<kF16m6, kConv, 1, 4, 4, 1, 2>(a, gx, s);
+    }
+    if (p.ksplit == 2 && p.nb == 1 && p.nwaves == 4) return launchOne<kF16m6, kConv, 1, 4, 4, 1, 2>(a, gx, s);
+    if (p.msplit == 2 && p.nb == 1 && p.nwaves == 4) return launchOne<kF16m6, kConv, 1, 4, 4, 2>(a, gx, s);
+#define NSG_CASE(NB_, NW_) \
+    if (p.nb == NB_ && p.nwaves == NW_) return launchOne<kF16m6, kConv, NB_, 4, NW_>(a, gx, s);
+    NSG_CASE(2, 4) NSG_CASE(2, 3) NSG_CASE(2, 2) NSG_CASE(2, 1)
+    NSG_CASE(1, 4) NSG_CASE(1, 3) NSG_CASE(1, 2) NSG_CASE(1, 1)
+#undef NSG_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launchTrunkF16m6(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s) {
+    const int gx = (batch + p.nb - 1) / p.nb;
+    if (p.nfrag == 4 && p.nb == 2 && p.nwaves == 4) return launchTrunkOne<kF16m6, 2, 4, 4>(layers, n, gx, s);
+    if (p.nfrag == 4 && p.nb == 1 && p.nwaves == 4) return launchTrunkOne<kF16m6, 1, 4, 4>(layers, n, gx, s);
+    if (p.nfrag == 4 && p.nb == 2 && p.nwaves == 3) return launchTrunkOne<kF16m6, 2, 4, 3>(layers, n, gx, s);
+    if (p.nfrag == 4 && p.nb == 1 && p.nwaves == 3) return launchTrunkOne<kF16m6, 1, 4, 3>(layers, n, gx, s);
+    return hipErrorInvalidValue;
+}
+
+} // namespace tile
+} // namespace nsg

@@ -2,6 +2,8 @@
 // precision dispatch, weight packing, and the small value-output kernel.
 #include "mfma_tile.h"
 
+#include <algorithm>
+#include <cmath>
 #include <stdlib.h>
 #include <string.h>
 
@@ -98,6 +100,7 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
     a.outF16x3 = outF16x3 ? 1 : 0;
     switch (prec) {
     case kF16m8: return tile::launchConvF16m8(a, batch, plan, stream);
+    case kF16m6: return tile::launchConvF16m6(a, batch, plan, stream);
     case kFp32: return tile::launchConvFp32(a, batch, plan, stream);
     case kFp16: return tile::launchConvFp16(a, batch, plan, stream);
     case kBf16: return tile::launchConvBf16(a, batch, plan, stream);
@@ -139,6 +142,7 @@ hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
     case kBf16: return tile::launchTrunkBf16(L, nLayers, batch, plan, stream);
     case kF16x3: return tile::launchTrunkF16x3(L, nLayers, batch, plan, stream);
     case kF16m8: return tile::launchTrunkF16m8(L, nLayers, batch, plan, stream);
+    case kF16m6: return tile::launchTrunkF16m6(L, nLayers, batch, plan, stream);
     }
     return hipErrorInvalidValue;
 }
@@ -349,10 +353,49 @@ uint8_t hostF32ToE4m3(float v) {
     return sign | (uint8_t)(((ex2 + 7) << 3) | (mant & 7));
 }
 
-// kF16m8 conv weights (see kernels.h): per chunk pair (A, B) and tap t the slabs A.m_t, B.m_t, X_t
+// e2m3 (fp6: 1 sign, 2 exponent, 3 mantissa bits, bias 1, max 7.5), round to nearest even, saturating;
+// the value is already divided by its block scale.
+uint8_t hostF32ToE2m3(float v) {
+    const uint8_t sign = std::signbit(v) ? 0x20 : 0;
+    float a = std::fabs(v);
+    if (!(a == a) || a >= 7.5f) return sign | 0x1f;
+    int ex = 0; // a in [2^ex, 2^(ex+1)), clamped to the format's three binades; below 1: subnormal step 1/8
+    if (a >= 4.f) ex = 2; else if (a >= 2.f) ex = 1;
+    const float step = std::ldexp(1.f, ex - 3);
+    const float r = std::nearbyint(a / step) * step; // ties to even
+    if (r >= 7.5f) return sign | 0x1f;
+    if (r < 1.f) return sign | (uint8_t)std::lrint(r * 8.f);
+    int e2 = r >= 4.f ? 2 : (r >= 2.f ? 1 : 0);
+    const int mant = (int)std::lrint(r / std::ldexp(1.f, e2 - 3)) - 8;
+    return sign | (uint8_t)(((e2 + 1) << 3) | (mant & 7));
+}
+
+// The MX operand of one lane in the kF16m6 layout: 32 values -> 24 bytes of e2m3 codes (value j at
+// bits [6j, 6j+6)), then the E8M0 exponent of the block (OCP MX rule: floor(log2(max|v|)) - 2), 7 bytes pad.
+void packE2m3Block(const float* v, unsigned char* out32) {
+    float maxAbs = 0.f;
+    for (int j = 0; j < 32; ++j) maxAbs = std::fmax(maxAbs, std::fabs(v[j]));
+    int e8 = 0;
+    if (maxAbs > 0.f && std::isfinite(maxAbs)) {
+        int e;
+        (void)std::frexp(maxAbs, &e); // maxAbs in [2^(e-1), 2^e)
+        e8 = std::min(254, std::max(1, e - 1 - 2 + 127));
+    }
+    memset(out32, 0, 32);
+    const float inv = std::ldexp(1.f, 127 - e8);
+    for (int j = 0; j < 32; ++j) {
+        const unsigned code = e8 ? hostF32ToE2m3(v[j] * inv) : 0u;
+        const int bit = 6 * j;
+        out32[bit / 8] |= (unsigned char)(code << (bit % 8));
+        if (bit % 8 > 2) out32[bit / 8 + 1] |= (unsigned char)(code >> (8 - bit % 8));
+    }
+    out32[24] = (unsigned char)e8;
+}
+
+// kF16m8 / kF16m6 conv weights (see kernels.h): per chunk pair (A, B) and tap t the slabs A.m_t, B.m_t, X_t
 // in stream order.
 void packTileWeightsM8(WeightGetter get, const void* ctx, int taps, int kReal, int kdim, int cout,
-                       float scale, unsigned char* out) {
+                       float scale, unsigned char* out, bool fp6) {
     const int npairs = kdim / 64;
     const int nft = cout / 16;
     const size_t recBytes = (size_t)nft * 64 * 16; // one record set: nft fragments x 64 lanes x 16 B
@@ -376,6 +419,26 @@ void packTileWeightsM8(WeightGetter get, const void* ctx, int taps, int kReal, i
                     }
                 ++r;
             }
+            if (fp6) { // MX slab, kF16m6: k-group g = (chunk g>>1, term g&1), one 32-byte e2m3 block per lane
+                for (int nf = 0; nf < nft; ++nf)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int rho = lane & 15, g = lane >> 4, n = chan(nf, rho);
+                        const int c = 2 * cp + (g >> 1);
+                        float v32[32];
+                        for (int j = 0; j < 32; ++j) {
+                            // term 0: w_lo against the x_hi block (channels in order); term 1: the copy of
+                            // w_hi against the x_lo block, whose slots hold channels 16..31, 0..15
+                            const int ch = (g & 1) ? (j + 16) % 32 : j;
+                            const float v = wval(n, c * 32 + ch, t);
+                            const _Float16 h = (_Float16)v;
+                            v32[j] = (g & 1) ? (float)h : v - (float)h;
+                        }
+                        unsigned char blk[32];
+                        packE2m3Block(v32, blk);
+                        for (int h16 = 0; h16 < 2; ++h16)
+                            memcpy(out + r * recBytes + (((size_t)nf * 2 + h16) * 64 + lane) * 16, blk + 16 * h16, 16);
+                    }
+            } else
             for (int nf = 0; nf < nft; ++nf) // MX slab: k-group g = (chunk g>>1, term g&1), 32 fp8 per lane
                 for (int h16 = 0; h16 < 2; ++h16)
                     for (int lane = 0; lane < 64; ++lane) {
@@ -405,8 +468,8 @@ void packTileWeights(WeightGetter get, const void* ctx, int taps, int kReal,
     const int per = (prec == kFp32) ? 4 : 8; // values per record
     unsigned char* out = (unsigned char*)dst;
     memset(out, 0, tileWeightRecords(taps, kdim, cout, prec) * 16);
-    if (prec == kF16m8) {
-        packTileWeightsM8(get, ctx, taps, kReal, kdim, cout, scale, out);
+    if (isMx(prec)) {
+        packTileWeightsM8(get, ctx, taps, kReal, kdim, cout, scale, out, prec == kF16m6);
         return;
     }
     for (int c = 0; c < nkc; ++c)

@@ -298,7 +298,7 @@ void packLayer(nsg::WeightGetter get, const void* ctx, int taps, int kReal, int 
                int coutReal, int prec, std::vector<unsigned char>* host, float* accScale) {
     host->assign(nsg::tileWeightRecords(taps, kdim, cout, prec) * 16, 0);
     float scale = 1.f;
-    if (prec == nsg::kF16x3 || prec == nsg::kF16m8) {
+    if (prec == nsg::kF16x3 || nsg::isMx(prec)) {
         // power-of-two scale putting the largest |w| in [2^8, 2^9): hi and lo of every
         // weight that matters stay in f16's normal range; undone exactly by accScale
         float maxAbs = 0.f;
@@ -351,7 +351,7 @@ __global__ void delayKernel(unsigned long long ticks) {
 int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& plan, hipStream_t s,
                  bool stampsOk, hipEvent_t trunkBegin = nullptr, hipEvent_t trunkEnd = nullptr) {
     // kF16m8 runs full tiles only; smaller launch plans use the kF16x3 copy of the trunk
-    const bool x3Fallback = (ev->prec == nsg::kF16m8 && plan.nfrag != 4);
+    const bool x3Fallback = (nsg::isMx(ev->prec) && plan.nfrag != 4);
     const int prec = x3Fallback ? (int)nsg::kF16x3 : ev->prec;
     const ConvLayer& stem = x3Fallback ? ev->W->stemX3 : ev->W->stem;
     const std::vector<ConvLayer>& conv1 = x3Fallback ? ev->W->conv1X3 : ev->W->conv1;
@@ -415,11 +415,11 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // kF16m8 keeps four image buffers in LDS (125 KB for two boards): a CU holds one two-board
     // workgroup, so where the channel count only allows two-wave workgroups (F = 384) one-board
     // tiles (74 KB) keep all four SIMDs busy with two workgroups per CU
-    if (ev->prec == nsg::kF16m8 && plan.nfrag == 4 && plan.nwaves <= 2 && ev->tuning.nb == 0) plan.nb = 1;
+    if (nsg::isMx(ev->prec) && plan.nfrag == 4 && plan.nwaves <= 2 && ev->tuning.nb == 0) plan.nb = 1;
     // Mid batches -- the engine's default batch of 128 and its benchmark's 60..159 -- run kF16m8
     // one-board tiles whose four waves are two row groups x two 64-channel groups (two workgroups per
     // board) wherever those fill more than half the CUs in one round of workgroups
-    if (ev->prec == nsg::kF16m8 && plan.nfrag != 4 && ev->F % 128 == 0 && ev->tuning.nfrag == 0 &&
+    if (nsg::isMx(ev->prec) && plan.nfrag != 4 && ev->F % 128 == 0 && ev->tuning.nfrag == 0 &&
         ev->tuning.msplit != 1) {
         const long cus = ev->prop.multiProcessorCount;
         const long wgM8 = (long)B * (ev->F / 128);
@@ -581,7 +581,7 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
                                 nullptr, y, N.F, N.F, 1, N.conv1[k].accScale);
             nsg::fillTrunkLayer(host.data(), 2 + 2 * k, y, N.conv2[k].w.p, (const float*)N.conv2[k].bias.p,
                                 x, z, N.F, N.F, 1, N.conv2[k].accScale,
-                                prec == nsg::kF16m8 && k == N.blocks - 1);
+                                nsg::isMx(prec) && k == N.blocks - 1);
             void* t = x; x = z; z = t;
         }
         if ((rc = ev->trunkLayers.alloc(host.size(), false))) return rc;
@@ -676,7 +676,7 @@ int nsg_destroy(nsg_evaluator* ev) {
 int nsg_set_precision(nsg_evaluator* ev, int precision) {
     if (!ev) return fail(NSG_E_INVALID, "null evaluator");
     if (ev->loaded) return fail(NSG_E_INVALID, "precision must be chosen before nsg_load");
-    if (precision < NSG_PRECISION_FP32 || precision > NSG_PRECISION_F16M8)
+    if (precision < NSG_PRECISION_FP32 || precision > NSG_PRECISION_F16M6)
         return fail(NSG_E_INVALID, "unknown precision %d", precision);
     ev->prec = precision;
     return NSG_OK;
@@ -743,22 +743,22 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
             float accScale = 1.f;
         };
         W->conv1.resize(nv.blocks); W->conv2.resize(nv.blocks);
-        if (prec == nsg::kF16m8) { W->conv1X3.resize(nv.blocks); W->conv2X3.resize(nv.blocks); }
+        if (nsg::isMx(prec)) { W->conv1X3.resize(nv.blocks); W->conv2X3.resize(nv.blocks); }
         std::vector<Job> jobs;
         auto add = [&](const float* w, const float* bn, int cinReal, int kdim, ConvLayer* L, ConvLayer* Lx3) {
             Job j;
             foldBn(bn, nv.F, nv.eps, &j.scale, &j.bias);
             j.w = w; j.cinReal = cinReal; j.kdim = kdim; j.prec = prec; j.L = L;
             jobs.push_back(j);
-            if (prec == nsg::kF16m8) { // the f16x3 copy of the trunk (small batches)
+            if (nsg::isMx(prec)) { // the f16x3 copy of the trunk (small batches)
                 j.prec = nsg::kF16x3; j.L = Lx3;
                 jobs.push_back(std::move(j));
             }
         };
         add(nv.stemW, nv.stemBn, nv.cin, W->cpad, &W->stem, &W->stemX3);
         for (int k = 0; k < nv.blocks; ++k) {
-            add(nv.w1[k], nv.bn1[k], nv.F, nv.F, &W->conv1[k], prec == nsg::kF16m8 ? &W->conv1X3[k] : nullptr);
-            add(nv.w2[k], nv.bn2[k], nv.F, nv.F, &W->conv2[k], prec == nsg::kF16m8 ? &W->conv2X3[k] : nullptr);
+            add(nv.w1[k], nv.bn1[k], nv.F, nv.F, &W->conv1[k], nsg::isMx(prec) ? &W->conv1X3[k] : nullptr);
+            add(nv.w2[k], nv.bn2[k], nv.F, nv.F, &W->conv2[k], nsg::isMx(prec) ? &W->conv2X3[k] : nullptr);
         }
         std::atomic<size_t> next{0};
         auto work = [&]() {

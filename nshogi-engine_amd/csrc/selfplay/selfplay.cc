@@ -63,7 +63,7 @@ class Arena {
 class Game {
  public:
     // Slot: this game slot's number among the run's Stride concurrent slots; its k-th game has id Slot + k * Stride
-    Game(Engine* E, uint64_t Slot, uint64_t Stride) : Eng(E), GameId(Slot), Stride(Stride) { newGame(false); }
+    Game(Engine* E, Engine::WorkerCtx* C, uint64_t Slot, uint64_t Stride) : Eng(E), Ctx(C), GameId(Slot), Stride(Stride) { newGame(false); }
     Game(const Game&) = delete;
     Game& operator=(const Game&) = delete;
 
@@ -328,7 +328,7 @@ class Game {
         }
         // checkmate by search (worker.cc:349-358: solver::dfs::solve(State, 3) at every non-root leaf)
         if (Eng->Opt.MateSearch && Leaf != Root && !S.findMate(3, true, &L).isNone()) {
-            ++Eng->St.MatesFound;
+            ++Ctx->St.MatesFound;
             setTerminal(1.0f, 0.0f);
             return false;
         }
@@ -337,10 +337,10 @@ class Game {
         Leaf->Edges = static_cast<Edge*>(Tree.alloc(sizeof(Edge) * (std::size_t)L.size()));
         for (int I = 0; I < L.size(); ++I) Leaf->Edges[I] = Edge{L[I].move16(), 0.0f, nullptr};
         if (Eng->Cache) { // worker.cc:367-378
-            EvalCache::Info& E = Eng->CacheScratch;
+            EvalCache::Info& E = Ctx->Scratch;
             if (Eng->Cache->load(S.hash(), &E) && E.NumMoves == Leaf->NumChildren) {
                 std::memcpy(Logits, E.Policy, Leaf->NumChildren * sizeof(float));
-                ++Eng->St.CacheHits;
+                ++Ctx->St.CacheHits;
                 finishEvaluation(Leaf->NumChildren, E.WinRate, E.DrawRate);
                 return false;
             }
@@ -393,7 +393,7 @@ class Game {
             ++N->Visits;
         }
         undoToRoot();
-        ++Eng->St.Playouts;
+        ++Ctx->St.Playouts;
         if (Eng->Opt.Gumbel) gumbelAfterBackprop();
         else if (Root->NumChildren == 1 || Root->Visits >= Budget) Ph = Phase::Transition;
         else Ph = Phase::LeafSelection;
@@ -439,17 +439,17 @@ class Game {
         FullSearchAt.push_back(FullSearch ? 1 : 0); // Frame::DidFullSearch (frame.h), read by saveworker.cc:172-174
         S.doMove(M);
         ++GameMoves;
-        ++Eng->St.Moves;
-        Eng->Digest += mix64(mix64(GameId + 0x51ed270b) ^ ((uint64_t)GameMoves << 32) ^ M.V);
+        ++Ctx->St.Moves;
+        Ctx->Digest += mix64(mix64(GameId + 0x51ed270b) ^ ((uint64_t)GameMoves << 32) ^ M.V);
         Ph = Phase::Judging;
     }
 
     void finish(Color Winner) {
-        if (Winner == shogi::Black) ++Eng->St.GamesBlack;
-        else if (Winner == shogi::White) ++Eng->St.GamesWhite;
-        else ++Eng->St.GamesDraw;
-        Eng->St.MovesOfFinishedGames += GameMoves;
-        if (Eng->Teacher) Eng->St.TeacherRecords += Eng->Teacher->saveGame(MoveHistory, FullSearchAt, Config, Winner);
+        if (Winner == shogi::Black) ++Ctx->St.GamesBlack;
+        else if (Winner == shogi::White) ++Ctx->St.GamesWhite;
+        else ++Ctx->St.GamesDraw;
+        Ctx->St.MovesOfFinishedGames += GameMoves;
+        if (Eng->Teacher) Ctx->St.TeacherRecords += Eng->Teacher->saveGame(MoveHistory, FullSearchAt, Config, Winner);
         if (Eng->Log) Eng->Log->add(GameId, Winner, MoveHistory);
         newGame();
     }
@@ -465,13 +465,13 @@ class Game {
         if (L.size() == 0) return finish(~S.sideToMove());
         if (S.ply() >= Config.MaxPly) return finish(shogi::NoColor);
         if (Eng->Opt.DfpnNodes) { // worker.cc:516-524: a proven mate ends the game with the mating move played
-            const Move Mate = Eng->Solver.solve(S, Eng->Opt.DfpnNodes);
-            Eng->St.DfpnNodes += Eng->Solver.nodes();
+            const Move Mate = Ctx->Solver.solve(S, Eng->Opt.DfpnNodes);
+            Ctx->St.DfpnNodes += Ctx->Solver.nodes();
             if (!Mate.isNone()) {
                 const Color Winner = S.sideToMove();
                 FullSearch = true; // pushDidFullSearch(true)
                 playMove(Mate);
-                ++Eng->St.DfpnMates;
+                ++Ctx->St.DfpnMates;
                 return finish(Winner);
             }
         }
@@ -479,6 +479,7 @@ class Game {
     }
 
     Engine* Eng;
+    Engine::WorkerCtx* Ctx; // the worker that owns this game slot
     uint64_t GameId; // of the game being played: slot + k * Stride
     uint64_t Stride;
     Arena Tree;
@@ -505,13 +506,26 @@ struct Engine::Group {
     std::vector<std::unique_ptr<Game>> Games;
     std::unique_ptr<evaluate::Evaluator> Ev;
     std::vector<int> Pending;
+    std::vector<std::size_t> Counts; // leaves found per worker in the last collect
     std::size_t Count = 0;
     bool InFlight = false;
 };
 
+int Engine::ownerOf(std::size_t GameIndex, std::size_t Games) const {
+    // worker W owns the games [Games * W / Workers, Games * (W + 1) / Workers)
+    const std::size_t W = (std::size_t)Opt.Workers;
+    std::size_t Guess = GameIndex * W / Games;
+    while (Guess + 1 < W && Games * (Guess + 1) / W <= GameIndex) ++Guess;
+    while (Guess > 0 && Games * Guess / W > GameIndex) --Guess;
+    return (int)Guess;
+}
+
 Engine::Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& O, uint64_t EngineIndex, bool PinMemory,
                EvalCache* SharedCache)
     : Opt(O), Cache(SharedCache) {
+    if (Opt.Workers < 1) Opt.Workers = 1;
+    if (Opt.Workers > Opt.GamesPerGroup) Opt.Workers = Opt.GamesPerGroup;
+    for (int W = 0; W < Opt.Workers; ++W) Ctx.push_back(std::make_unique<WorkerCtx>());
     infer::Infer* Exec[2] = {Exec0, Exec1};
     const uint64_t Mine = 2 * (uint64_t)Opt.GamesPerGroup;
     const uint64_t Stride = Opt.TotalSlots ? Opt.TotalSlots : Mine;
@@ -520,34 +534,106 @@ Engine::Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& O, uint6
         Groups[G]->Ev = std::make_unique<evaluate::Evaluator>(EngineIndex * 2 + G, shogi::NumFeaturePlanes,
                                                               (std::size_t)Opt.GamesPerGroup, Exec[G], PinMemory);
         Groups[G]->Pending.resize(Opt.GamesPerGroup);
+        Groups[G]->Counts.assign((std::size_t)Opt.Workers, 0);
         for (int I = 0; I < Opt.GamesPerGroup; ++I)
             Groups[G]->Games.push_back(std::make_unique<Game>(
-                this, EngineIndex * Mine + (uint64_t)G * (uint64_t)Opt.GamesPerGroup + (uint64_t)I, Stride));
+                this, Ctx[(std::size_t)ownerOf((std::size_t)I, (std::size_t)Opt.GamesPerGroup)].get(),
+                EngineIndex * Mine + (uint64_t)G * (uint64_t)Opt.GamesPerGroup + (uint64_t)I, Stride));
     }
+    for (int W = 1; W < Opt.Workers; ++W) Pool.emplace_back([this, W]() { workerLoop(W); });
 }
 
 Engine::~Engine() {
     drain();
+    Quit.store(true, std::memory_order_release);
+    Epoch.fetch_add(1, std::memory_order_release);
+    for (auto& T : Pool) T.join();
+}
+
+void Engine::workerLoop(int W) {
+    uint64_t Seen = 0;
+    for (;;) {
+        // steps are about a millisecond apart: spin, but give the core away now and then
+        for (unsigned Spin = 0; Epoch.load(std::memory_order_acquire) == Seen; ++Spin)
+            if ((Spin & 63) == 63) std::this_thread::yield();
+        ++Seen;
+        if (Quit.load(std::memory_order_acquire)) return;
+        (*Task)(W);
+        Done.fetch_add(1, std::memory_order_release);
+    }
+}
+
+void Engine::parallelFor(const std::function<void(int)>& Fn) {
+    if (Pool.empty()) {
+        Fn(0);
+        return;
+    }
+    Task = &Fn;
+    Done.store(0, std::memory_order_relaxed);
+    Epoch.fetch_add(1, std::memory_order_release);
+    Fn(0);
+    while (Done.load(std::memory_order_acquire) < (int)Pool.size()) {
+    }
+}
+
+Stats Engine::stats() const {
+    Stats S = St;
+    for (const auto& C : Ctx) {
+        const Stats& X = C->St;
+        S.CacheHits += X.CacheHits; S.Playouts += X.Playouts; S.Moves += X.Moves; S.MatesFound += X.MatesFound;
+        S.DfpnMates += X.DfpnMates; S.DfpnNodes += X.DfpnNodes; S.GamesBlack += X.GamesBlack;
+        S.GamesWhite += X.GamesWhite; S.GamesDraw += X.GamesDraw; S.MovesOfFinishedGames += X.MovesOfFinishedGames;
+        S.TeacherRecords += X.TeacherRecords;
+    }
+    return S;
+}
+
+uint64_t Engine::moveDigest() const {
+    uint64_t D = 0;
+    for (const auto& C : Ctx) D += C->Digest;
+    return D;
 }
 
 void Engine::apply(Group& G) {
     if (!G.InFlight) return;
     G.Ev->await();
-    for (std::size_t K = 0; K < G.Count; ++K) {
-        G.Games[G.Pending[K]]->setEvaluation(G.Ev->getPolicy() + K * shogi::MoveIndexMax,
-                                             G.Ev->getWinRate()[K], G.Ev->getDrawRate()[K]);
-    }
+    const std::size_t Games = G.Games.size();
+    parallelFor([&](int W) { // every game's results are applied by the worker that owns it
+        for (std::size_t K = 0; K < G.Count; ++K) {
+            const std::size_t I = (std::size_t)G.Pending[K];
+            if (ownerOf(I, Games) != W) continue;
+            G.Games[I]->setEvaluation(G.Ev->getPolicy() + K * shogi::MoveIndexMax, G.Ev->getWinRate()[K],
+                                      G.Ev->getDrawRate()[K]);
+        }
+    });
     G.InFlight = false;
 }
 
 void Engine::collect(Group& G) {
-    std::size_t N = 0;
     static_assert(sizeof(FeaturePlane) == sizeof(ml::FeatureBitboard), "feature plane layout");
     auto* Slots = reinterpret_cast<FeaturePlane*>(G.Ev->getFeatureBitboards());
-    for (std::size_t I = 0; I < G.Games.size(); ++I) {
-        if (G.Games[I]->advanceUntilEvaluation(Slots + N * shogi::NumFeaturePlanes)) {
-            G.Pending[N++] = (int)I;
+    const std::size_t Games = G.Games.size(), W = (std::size_t)Opt.Workers;
+    // worker w advances its own games and packs their leaves from slot lo(w) on
+    parallelFor([&](int Wk) {
+        const std::size_t Lo = Games * (std::size_t)Wk / W, Hi = Games * ((std::size_t)Wk + 1) / W;
+        std::size_t N = 0;
+        for (std::size_t I = Lo; I < Hi; ++I) {
+            if (G.Games[I]->advanceUntilEvaluation(Slots + (Lo + N) * shogi::NumFeaturePlanes)) {
+                G.Pending[Lo + N++] = (int)I;
+            }
         }
+        G.Counts[(std::size_t)Wk] = N;
+    });
+    // close the gaps a worker left (a game that found nothing to evaluate: rare)
+    std::size_t N = 0;
+    for (std::size_t Wk = 0; Wk < W; ++Wk) {
+        const std::size_t Lo = Games * Wk / W, C = G.Counts[Wk];
+        if (Lo != N && C) {
+            std::memmove(Slots + N * shogi::NumFeaturePlanes, Slots + Lo * shogi::NumFeaturePlanes,
+                         C * shogi::NumFeaturePlanes * sizeof(FeaturePlane));
+            std::memmove(&G.Pending[N], &G.Pending[Lo], C * sizeof(int));
+        }
+        N += C;
     }
     G.Count = N;
     if (N == 0) return;
@@ -562,9 +648,10 @@ void Engine::step() {
         apply(*Groups[G]);   // results of this group's previous batch
         collect(*Groups[G]); // host search of this group while the other group's batch computes
     }
-    PubFinished.store(St.finished(), std::memory_order_relaxed);
-    PubEvaluations.store(St.Evaluations, std::memory_order_relaxed);
-    PubMoves.store(St.Moves, std::memory_order_relaxed);
+    const Stats S = stats();
+    PubFinished.store(S.finished(), std::memory_order_relaxed);
+    PubEvaluations.store(S.Evaluations, std::memory_order_relaxed);
+    PubMoves.store(S.Moves, std::memory_order_relaxed);
 }
 
 void Engine::drain() {
@@ -572,7 +659,7 @@ void Engine::drain() {
 }
 
 void Engine::run(const volatile bool* Stop, uint64_t MaxFinishedGames) {
-    while (!*Stop && (MaxFinishedGames == 0 || St.finished() < MaxFinishedGames)) step();
+    while (!*Stop && (MaxFinishedGames == 0 || stats().finished() < MaxFinishedGames)) step();
     drain();
 }
 

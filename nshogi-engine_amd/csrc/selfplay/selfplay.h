@@ -7,10 +7,13 @@
 // sequentialHalving (non-Gumbel part) :412-426, transition :528-610, judge
 // :477-526; Frame::setEvaluation frame.cc:93-136; PUCT worker.cc:688-715;
 // win-rate blending :726-770) with these deliberate differences:
-//   * one thread owns its games and steps them in two groups: while one group's
-//     leaf batch is on the GPU the thread searches the other group (the reference
+//   * one engine owns its games and steps them in two groups: while one group's
+//     leaf batch is on the GPU the engine searches the other group (the reference
 //     brackets a blocking GPU call with serial host loops,
-//     selfplay/evaluationworker.cc:69-117);
+//     selfplay/evaluationworker.cc:69-117).  The search between two batches is a fork-join over
+//     Options::Workers host threads, each advancing its own fixed share of the group's games
+//     (role of --num-search-workers, selfplay/main.cc:34-35), so the batch size stays the group
+//     size however many host threads it takes to keep the GPU fed;
 //   * every game has its own RNG seeded from (base seed, game id): the driver numbers its
 //     concurrent game slots 0..N-1 across all engines and slot s plays the games s, s+N, s+2N, ...
 //     Batch results are slot-independent, so a run is reproducible bit for bit, and -- when the
@@ -43,7 +46,9 @@
 #include <atomic>
 #include <cstdint>
 #include <memory>
+#include <functional>
 #include <random>
+#include <thread>
 #include <vector>
 
 namespace nshogi {
@@ -61,6 +66,7 @@ struct Options {
     int MaxPlyMax = 512 + 128;
     bool RandomDrawValue = true; // worker.cc:142-150
     uint64_t TotalSlots = 0;     // concurrent games of the whole run (all engines); 0 = this engine's own
+    int Workers = 1;             // host threads that advance one engine's games between two batches (fork-join)
     uint64_t DfpnNodes = 100000; // node budget of the df-pn mate solver run after every move (worker.cc:516); 0 = off
     bool MateSearch = true;      // mate-in-3 search by checks at every non-root leaf (worker.cc:349-358)
 };
@@ -125,27 +131,40 @@ class Engine {
     uint64_t publishedEvaluations() const { return PubEvaluations.load(std::memory_order_relaxed); }
     uint64_t publishedMoves() const { return PubMoves.load(std::memory_order_relaxed); }
 
-    const Stats& stats() const { return St; }
+    Stats stats() const; // summed over the engine's workers
     // order-independent digest of every move played so far (reproducibility checks): a wrapping sum
     // over (game id, ply, move), so engines' digests add up to the same total however the game slots
     // are spread over them
-    uint64_t moveDigest() const { return Digest; }
+    uint64_t moveDigest() const;
 
  private:
     struct Group;
+    // What one host thread of the engine owns: its games' counters, mate solver and cache scratch.
+    struct WorkerCtx {
+        Stats St;
+        uint64_t Digest = 0;
+        shogi::DfpnSolver Solver;
+        EvalCache::Info Scratch;
+    };
     void collect(Group& G);
     void apply(Group& G);
+    void parallelFor(const std::function<void(int)>& Fn); // Fn(worker) on every worker, caller = worker 0
+    void workerLoop(int W);
+    int ownerOf(std::size_t GameIndex, std::size_t Games) const;
 
     Options Opt;
-    Stats St;
+    Stats St; // engine-level counters: Batches, Evaluations
     TeacherWriter* Teacher = nullptr;
     GameLog* Log = nullptr;
-    shogi::DfpnSolver Solver;
-    uint64_t Digest = 0;
+    std::vector<std::unique_ptr<WorkerCtx>> Ctx;
+    std::vector<std::thread> Pool;
+    const std::function<void(int)>* Task = nullptr;
+    std::atomic<uint64_t> Epoch{0};
+    std::atomic<int> Done{0};
+    std::atomic<bool> Quit{false};
     std::atomic<uint64_t> PubFinished{0}, PubEvaluations{0}, PubMoves{0};
     std::unique_ptr<Group> Groups[2];
     EvalCache* Cache = nullptr;
-    EvalCache::Info CacheScratch;
     friend class Game;
 };
 

@@ -17,7 +17,9 @@
 // executor of every further GPU takes a peer copy over xGMI (nsg_load_shared).
 //
 // usage: selfplay [--executor hip|random|zero] [--weights model.onnx|file.nsgw] [--gpu 0] [--num-gpus 1]
-//                 [--threads 2] [--games-per-group 256] [--playouts 800]
+//                 [--threads 2] [--workers 1] [--games-per-group 256] [--playouts 800]
+//                 (--threads: engines per GPU, each with its own two batches in flight; --workers: host
+//                  threads per engine that advance its games between two batches)
 //                 [--seconds 30] [--max-games 0] [--seed 0] [--precision 3] [--mate-search 1] [--dfpn-nodes 100000]
 //                 [--evaluation-cache-memory-size 1024]   (MB per GPU shard, split over its caches; 0 = no cache)
 //                 [--share-evaluation-cache 0]
@@ -62,6 +64,7 @@ int main(int Argc, char* Argv[]) {
         else if (K == "--gpu") Gpu = std::stoi(V);
         else if (K == "--num-gpus") NumGpus = std::stoi(V);
         else if (K == "--threads") Threads = std::stoi(V);
+        else if (K == "--workers" || K == "--num-search-workers") Opt.Workers = std::stoi(V);
         else if (K == "--games-per-group") Opt.GamesPerGroup = std::stoi(V);
         else if (K == "--playouts" || K == "--num-playouts") Opt.NumPlayouts = std::stoi(V);
         else if (K == "--seconds") Seconds = std::stod(V);
@@ -159,7 +162,7 @@ int main(int Argc, char* Argv[]) {
     uint64_t Digest = 0;
     std::vector<uint64_t> EvalsPerGpu((std::size_t)NumGpus, 0);
     for (int E = 0; E < NumEngines; ++E) {
-        const auto& X = Engines[E]->stats();
+        const selfplay::Stats X = Engines[E]->stats();
         S.Evaluations += X.Evaluations; S.CacheHits += X.CacheHits; S.Batches += X.Batches;
         S.Playouts += X.Playouts; S.Moves += X.Moves; S.GamesBlack += X.GamesBlack;
         S.GamesWhite += X.GamesWhite; S.GamesDraw += X.GamesDraw;
@@ -178,7 +181,7 @@ int main(int Argc, char* Argv[]) {
         break;
     }
     const double Fin = (double)S.finished();
-    std::cout << "{\"executor\": \"" << Executor << "\", \"num_gpus\": " << NumGpus << ", \"threads\": " << Threads
+    std::cout << "{\"executor\": \"" << Executor << "\", \"num_gpus\": " << NumGpus << ", \"threads\": " << Threads << ", \"workers\": " << Opt.Workers
               << ", \"games_per_group\": " << Opt.GamesPerGroup << ", \"concurrent_games\": " << Opt.TotalSlots
               << ", \"playouts_per_move\": " << Opt.NumPlayouts << ", \"seconds\": " << Dt
               << ", \"games_finished\": " << S.finished() << ", \"games_per_sec\": " << Fin / Dt
