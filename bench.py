@@ -33,16 +33,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Default precision f16m8: the fastest path that meets the north_star's 1e-3 parity bar
-# (measured 1.3e-4 vs the CPU oracle on this net; f16x3 and f32 measure 5e-6 and are reported
-# beside it; plain f16 / bf16 do not meet the bar).
+# Default precision f16m6: the fastest path that meets the north_star's 1e-3 parity bar
+# (measured 1.5e-4 vs the CPU oracle on this net, profiles/r02/b_accuracy_all_precisions_b512.jsonl;
+# f16m8 1.5e-4; f16x3 and f32 measure 6e-6 and are reported beside it; plain f16 / bf16 do not meet
+# the bar).
 # MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2516.6, "bf16": 2516.6, "f16x3": 2516.6, "f16m8": 2516.6}
+PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2516.6, "bf16": 2516.6, "f16x3": 2516.6, "f16m8": 2516.6, "f16m6": 2516.6}
 DTYPE_NAME = {"fp32": "f32", "fp16": "f16", "bf16": "bf16", "f16x3": "f16x3 (split f16 hi/lo, f32 accumulate)",
-              "f16m8": "f16m8 (f16 main term + fp8 MX correction terms, f32 accumulate)"}
+              "f16m8": "f16m8 (f16 main term + fp8 MX correction terms, f32 accumulate)",
+              "f16m6": "f16m6 (f16 main term + e2m3 MX correction terms with per-32-channel E8M0 scales, f32 accumulate)"}
 # matrix-pipe work per algorithmic MAC in units of one f16 MFMA MAC (the MX instruction
 # retires 4x the K of the f16 one in 2x its cycles; per tap and chunk pair 2 f16 + 1 MX slab)
-MFMA_UNITS = {"fp32": 1, "fp16": 1, "bf16": 1, "f16x3": 3, "f16m8": 2.0}
+# (f16m6: the e2m3 form of the MX instruction retires that K in ONE f16 MFMA's cycles: 2 f16 + 1 MX slab = 1.5)
+MFMA_UNITS = {"fp32": 1, "fp16": 1, "bf16": 1, "f16x3": 3, "f16m8": 2.0, "f16m6": 1.5}
 
 
 def cpu_baseline(seconds=12.0):
@@ -178,16 +181,16 @@ def quick_rate(nsg, local_rank, blob, bb, B, precision, steps=5):
 SELFPLAY_BIN = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "selfplay", "selfplay")
 
 
-def selfplay_leg(weights_path, gpu, seconds, threads, precision, playouts=800, games_per_group=256):
+def selfplay_leg(weights_path, gpu, seconds, threads, precision, playouts=800, games_per_group=256, workers=1):
     """BASELINE metric #2 on this rank's GPU: the self-play driver (csrc/selfplay) with
     the reference's option names/values of config 4 (--num-playouts 800, batch = games per
     group).  games/sec = finished games / elapsed (saveworker.cc:135-137).  Never raises: a rank
     whose driver fails or hangs must still reach the collectives that follow."""
     import subprocess
-    prec = {"fp32": 0, "fp16": 1, "bf16": 2, "f16x3": 3, "f16m8": 4}[precision]
+    prec = {"fp32": 0, "fp16": 1, "bf16": 2, "f16x3": 3, "f16m8": 4, "f16m6": 5}[precision]
     try:
         r = subprocess.run([SELFPLAY_BIN, "--executor", "hip", "--weights", weights_path, "--gpu", str(gpu),
-                            "--threads", str(threads), "--games-per-group", str(games_per_group),
+                            "--threads", str(threads), "--workers", str(workers), "--games-per-group", str(games_per_group),
                             "--playouts", str(playouts), "--seconds", str(seconds), "--seed", "1",
                             "--precision", str(prec)], capture_output=True, text=True, timeout=seconds * 3 + 300)
         if r.returncode != 0:
@@ -213,8 +216,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--net", default="20x256", help="blocks x channels, e.g. 10x192, 20x256, 40x384")
     ap.add_argument("--batch", type=int, default=512)
-    ap.add_argument("--precision", default=os.environ.get("NSG_BENCH_PRECISION", "f16m8"),
-                    choices=["fp32", "fp16", "bf16", "f16x3", "f16m8"])
+    ap.add_argument("--precision", default=os.environ.get("NSG_BENCH_PRECISION", "f16m6"),
+                    choices=["fp32", "fp16", "bf16", "f16x3", "f16m8", "f16m6"])
     ap.add_argument("--positions", default="startpos", choices=["startpos", "distinct", "synthetic"],
                     help="startpos: the initial position in every slot (bench/batchsize.cc:47-59, the default); "
                          "distinct: B distinct positions of random-playout games; synthetic: seeded random bitboards")
@@ -225,6 +228,9 @@ def main():
     # BASELINE configs[3]: 256 concurrent games per GPU = 1 thread x 2 groups x 128 games
     # (profiles/r01/h_selfplay_shape_256_games.txt)
     ap.add_argument("--selfplay-threads", type=int, default=1)
+    # host threads advancing the engine's games between two batches: one keeps up in the opening, two to
+    # three are needed once positions get busy (profiles/r02/a_selfplay_shape_workers.txt)
+    ap.add_argument("--selfplay-workers", type=int, default=3)
     ap.add_argument("--selfplay-games-per-group", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
@@ -322,7 +328,7 @@ def main():
         barrier()
         ev.close()  # free this process's evaluator before the self-play process allocates its own
         mine = selfplay_leg(wpath, local_rank, args.selfplay_seconds, args.selfplay_threads, args.precision,
-                            games_per_group=args.selfplay_games_per_group)
+                            games_per_group=args.selfplay_games_per_group, workers=args.selfplay_workers)
         try:
             os.remove(wpath)
         except OSError:
@@ -341,7 +347,7 @@ def main():
         else:
             sp = dict(tot, **{k: mine[k] for k in ("avg_batch", "cache_hit_ratio", "avg_game_length", "playouts_per_move",
                                                    "seconds", "window_seconds") if k in mine},
-                      threads_per_gpu=mine.get("threads"),
+                      threads_per_gpu=mine.get("threads"), workers_per_thread=mine.get("workers"),
                       note="AlphaZero-mode self-play from startpos on this build's own shogi core; synthetic "
                            "(untrained) weights, so games end early by repetition: games/sec is a plumbing number, "
                            "evals/playouts per sec are the load.  games_per_sec = finished / elapsed from a cold "
@@ -452,7 +458,7 @@ def main():
             out["roofline_extract"] = extract_roofline(nsg, bb, B)
         if not args.no_host_path and world == 1:
             out["other_precisions_evals_per_sec"] = {
-                p: quick_rate(nsg, local_rank, blob, bb, B, p) for p in ("fp32", "f16x3", "f16m8", "fp16", "bf16")
+                p: quick_rate(nsg, local_rank, blob, bb, B, p) for p in ("fp32", "f16x3", "f16m8", "f16m6", "fp16", "bf16")
                 if p != args.precision}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

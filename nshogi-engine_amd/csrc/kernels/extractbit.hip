@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void extractAct(
 }
 
 // ---- kF16m6 trunk input: per (square, 32-channel chunk) one 128-byte row
-// [32 x f16 hi][e2m3(hi) block][e2m3(lo) block, channels 16..31, 0..15], each block 24 B of codes +
+// [32 x f16 hi][e2m3(hi) block][e2m3(lo) block], each block 24 B of codes +
 // its E8M0 exponent (kernels.h).  One thread per (square, chunk); values are plane bits and four
 // scalar planes, so a software encoder is plenty here (the trunk's epilogue uses the packed
 // conversion instructions).
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void extractActM6(
             }
             const _Float16 h = (_Float16)v;
             hi[i] = (float)h;
-            lo[(i + 16) & 31] = v - (float)h; // lo block slots: channels 16..31, then 0..15
+            lo[i] = v - (float)h;
             const uint32_t hb = __builtin_bit_cast(uint16_t, h);
             if (i & 1) hbits[i >> 1] |= hb << 16; else hbits[i >> 1] = hb;
         }

@@ -34,9 +34,7 @@ namespace nsg {
 // profiles/r02/a_fp6_probe.txt): 1.5 MFMA units per MAC.  No fixed scales, hence no clamp
 // window: the block exponent follows the data.  Activations: 128-byte chunks of 32 channels,
 // [32 x f16 hi][24 B: e2m3(hi), channel order 0..31][1 B E8M0][7 B pad]
-//              [24 B: e2m3(lo), channel order 16..31, 0..15][1 B E8M0][7 B pad]
-// (the lo block is rotated because the lane that encodes it holds channels 16..31 itself and
-// receives 0..15 from its neighbour; the weight copy that multiplies it is packed in the same order).
+//              [24 B: e2m3(lo), channel order 0..31][1 B E8M0][7 B pad]
 enum Precision { kFp32 = 0, kFp16 = 1, kBf16 = 2, kF16x3 = 3, kF16m8 = 4, kF16m6 = 5 };
 // the two split-precision trunk formats that run their correction terms on the MX instruction
 constexpr bool isMx(int prec) { return prec == kF16m8 || prec == kF16m6; }

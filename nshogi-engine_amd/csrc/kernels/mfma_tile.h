@@ -1020,18 +1020,21 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                             }
                     } else if constexpr (kM6) {
                         // lo block -> 32 f16 (v_cvt_scalef32_pk32_f16_fp6 multiplies by the block scale); slots
-                        // 0..15 are the odd lane group's channels, 16..31 the even one's
+                        // 0..15 are the even lane group's channels, 16..31 the odd one's
                         typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
                         typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
-                        const u32x6 blk = {rp[2][0], rp[2][1], rp[2][2], rp[2][3], rp[3][0], rp[3][1]};
-                        const float sc = __uint_as_float((rp[3][2] & 0xffu) << 23);
+                        const u32x6 blk = {rp[2].x, rp[2].y, rp[2].z, rp[2].w, rp[3].x, rp[3].y};
+                        const float sc = __uint_as_float((rp[3].z & 0xffu) << 23);
                         u32x16 lh;
-                        asm volatile("v_cvt_scalef32_pk32_f16_fp6 %0, %1, %2" : "=&v"(lh) : "v"(blk), "v"(sc));
+                        asm("v_cvt_scalef32_pk32_f16_fp6 %0, %1, %2" : "=&v"(lh) : "v"(blk), "v"(sc));
                         const bool odd = (g & 1) != 0;
+                        const uint32_t le[8] = {lh.s0, lh.s1, lh.s2, lh.s3, lh.s4, lh.s5, lh.s6, lh.s7};
+                        const uint32_t lo8[8] = {lh.s8, lh.s9, lh.sa, lh.sb, lh.sc, lh.sd, lh.se, lh.sf};
+                        const uint32_t hh[8] = {rp[0].x, rp[0].y, rp[0].z, rp[0].w, rp[1].x, rp[1].y, rp[1].z, rp[1].w};
 #pragma unroll
                         for (int d = 0; d < 8; ++d) { // dword d of my half = channels 2d, 2d+1
-                            const uint32_t l2 = odd ? lh[d] : lh[8 + d];
-                            const uint32_t h2 = rp[d >> 2][d & 3];
+                            const uint32_t l2 = odd ? lo8[d] : le[d];
+                            const uint32_t h2 = hh[d];
                             v[2 * d] += f16BitsToF32((uint16_t)(h2 & 0xffffu)) + f16BitsToF32((uint16_t)(l2 & 0xffffu));
                             v[2 * d + 1] += f16BitsToF32((uint16_t)(h2 >> 16)) + f16BitsToF32((uint16_t)(l2 >> 16));
                         }
@@ -1092,16 +1095,22 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                             op[2 + k][i] = l2;
                         }
                     } else if constexpr (kM6) {
-                        // f16 hi pairs, f16 copies of lo; block maxima -> E8M0 exponents (OCP MX rule: exponent
-                        // of the maximum minus 2); the lane groups (g, g^1) of a chunk swap what the other needs
-                        // -- even lanes encode the hi block [own 0..15, neighbour's 16..31], odd lanes the lo block
-                        // [own 16..31, neighbour's 0..15] -- one packed conversion each.
+                        // f16 hi pairs and f16 copies of lo.  The lane groups (g, g^1) of a chunk trade what the
+                        // other needs with v_permlane16_swap (row r of one register <-> row r+1 of the other:
+                        // even rows end up with (own A, neighbour's A), odd rows with (neighbour's B, own B);
+                        // profiles/r02/a_permlane_probe.txt): with A = hi, B = lo, even lanes hold the chunk's
+                        // 32 hi values and odd lanes its 32 lo values, both in channel order, and the same
+                        // swap on the two maxima leaves each lane the maximum of ITS block.  E8M0 exponent =
+                        // exponent of the maximum minus 2 (OCP MX rule); one packed conversion per lane.
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
                         typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
                         typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
-                        uint32_t hp[8], lp[8];
                         float mh = 0.f, ml = 0.f;
+                        // (scalars in plain arrays, vectors built by initialiser lists: element-wise writes to a
+                        // 16-wide ext_vector in this loop compiled to compare/select chains, 2400 extra instructions)
+                        uint32_t hpv[8], sa[8], sb[8];
 #pragma unroll
                         for (int d = 0; d < 8; ++d) {
                             const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * d], floorV, 65000.f),
@@ -1109,31 +1118,27 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                             const f16x2 h = __builtin_convertvector(x, f16x2);
                             const f32x2 hx = __builtin_convertvector(h, f32x2);
                             const f32x2 lx = x - hx;
-                            hp[d] = __builtin_bit_cast(uint32_t, h);
-                            lp[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lx, f16x2));
+                            const uint32_t hp = __builtin_bit_cast(uint32_t, h);
+                            const uint32_t lp = __builtin_bit_cast(uint32_t, __builtin_convertvector(lx, f16x2));
+                            hpv[d] = hp;
                             mh = fmaxf(mh, fmaxf(fabsf(hx[0]), fabsf(hx[1])));
                             ml = fmaxf(ml, fmaxf(fabsf(lx[0]), fabsf(lx[1])));
+                            const u32x2v sw = __builtin_amdgcn_permlane16_swap(hp, lp, false, false);
+                            sa[d] = sw.x;
+                            sb[d] = sw.y;
                         }
-                        op[0] = u32x4{hp[0], hp[1], hp[2], hp[3]};
-                        op[1] = u32x4{hp[4], hp[5], hp[6], hp[7]};
-                        const bool odd = (g & 1) != 0;
-                        // 0x401F: ds_swizzle bit mode, lane ^ 16 (profiles/r02/a_fp6_cvt_probe2.txt)
-                        mh = fmaxf(mh, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(mh), 0x401F)));
-                        ml = fmaxf(ml, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ml), 0x401F)));
-                        const uint32_t ef = __float_as_uint(odd ? ml : mh) >> 23; // biased exponent of my block's maximum
+                        op[0] = u32x4{hpv[0], hpv[1], hpv[2], hpv[3]};
+                        op[1] = u32x4{hpv[4], hpv[5], hpv[6], hpv[7]};
+                        const u32x16 src = {sa[0], sa[1], sa[2], sa[3], sa[4], sa[5], sa[6], sa[7],
+                                            sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], sb[6], sb[7]};
+                        const u32x2v mm = __builtin_amdgcn_permlane16_swap(__float_as_uint(mh), __float_as_uint(ml), false, false);
+                        const uint32_t ef = (mm.x > mm.y ? mm.x : mm.y) >> 23; // non-negative floats order like their bits
                         const uint32_t e8 = ef > 3u ? ef - 2u : 1u;
-                        u32x16 src;
-#pragma unroll
-                        for (int d = 0; d < 8; ++d) {
-                            const uint32_t give = odd ? hp[d] : lp[d];  // what the neighbour's block needs from me
-                            src[d] = odd ? lp[d] : hp[d];               // my block, own half first
-                            src[8 + d] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)give, 0x401F);
-                        }
                         u32x6 blk;
                         const float sc = __uint_as_float(e8 << 23);
-                        asm volatile("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(blk) : "v"(src), "v"(sc));
-                        op[2] = u32x4{blk[0], blk[1], blk[2], blk[3]};
-                        op[3] = u32x4{blk[4], blk[5], e8, 0u};
+                        asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(blk) : "v"(src), "v"(sc));
+                        op[2] = u32x4{blk.s0, blk.s1, blk.s2, blk.s3};
+                        op[3] = u32x4{blk.s4, blk.s5, e8, 0u};
                     } else {
                         // two values per instruction where the ISA has a packed form (v_cvt_pk_f16_f32,
                         // v_pk_add_f32, v_pk_mul_f32); v_med3 needs no NaN-quieting of its inputs

@@ -426,10 +426,8 @@ void packTileWeightsM8(WeightGetter get, const void* ctx, int taps, int kReal, i
                         const int c = 2 * cp + (g >> 1);
                         float v32[32];
                         for (int j = 0; j < 32; ++j) {
-                            // term 0: w_lo against the x_hi block (channels in order); term 1: the copy of
-                            // w_hi against the x_lo block, whose slots hold channels 16..31, 0..15
-                            const int ch = (g & 1) ? (j + 16) % 32 : j;
-                            const float v = wval(n, c * 32 + ch, t);
+                            // term 0: w_lo against the x_hi block; term 1: the copy of w_hi against the x_lo block
+                            const float v = wval(n, c * 32 + j, t);
                             const _Float16 h = (_Float16)v;
                             v32[j] = (g & 1) ? (float)h : v - (float)h;
                         }

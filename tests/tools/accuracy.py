@@ -19,7 +19,7 @@ bb = nsg.synth.random_batch(a.batch, 86, seed=1)
 idx = np.linspace(0, a.batch - 1, a.sample).astype(int)
 po, vo, do = oracle_lib.load().net(blob).evaluate(bb[idx])
 res = {"net": a.net, "bn": a.bn, "policy_abs_max_ref": float(np.abs(po).max()), "policy_std_ref": float(po.std())}
-for prec in ("fp32", "f16x3", "f16m8", "fp16", "bf16"):
+for prec in ("fp32", "f16x3", "f16m8", "f16m6", "fp16", "bf16"):
     ev = nsg.Evaluator(0, a.batch, 86, precision=prec); ev.load_memory(blob)
     p, v, d = ev.compute_blocking(bb)
     res[prec] = {"policy_max_abs_err": float(np.abs(p[idx] - po).max()),
