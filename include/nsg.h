@@ -223,6 +223,17 @@ typedef struct nsg_info {
 } nsg_info;
 int nsg_get_info(nsg_evaluator* ev, nsg_info* info);
 
+/* Host statistics of this evaluator since creation: forward passes enqueued and
+ * positions in them -- average batch size = positions / batches, what the
+ * reference accumulates in mcts::Statistics (src/mcts/statistics.h:74-98:
+ * evaluationCount, batchSizeAccumulated) and prints after every search
+ * (src/protocol/usilogger.cc:79-83,129-134).  The self-play driver prints its own
+ * average batch size and cache-hit ratio (selfplayinfo.cc:51-57,72-78).
+ * Profiler markers: with NSG_ROCTX=1 in the environment every forward pass wraps
+ * its phases in roctx ranges nsg.h2d / nsg.planes / nsg.trunk / nsg.heads / nsg.d2h
+ * for `rocprofv3 --marker-trace`. */
+int nsg_get_stats(nsg_evaluator* ev, uint64_t* batches, uint64_t* positions);
+
 /* Launch plan of the most recent forward pass (tests and tuning): boards per
  * workgroup, 16-channel fragments per wave, waves per workgroup, and the number
  * of independent half-batch chains.  All zero before the first forward pass. */

@@ -96,6 +96,7 @@ def load_library():
                                      ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_uint64)]
     lib.nsg_get_info.argtypes = [vp, ctypes.POINTER(_Info)]
+    lib.nsg_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     ip = ctypes.POINTER(ctypes.c_int)
     lib.nsg_get_last_plan.argtypes = [vp, ip, ip, ip, ip]
     lib.nsg_get_last_trunk_precision.argtypes = [vp, ip]
@@ -281,6 +282,13 @@ class Evaluator:
         d = {k: getattr(s, k) for k, _ in _Info._fields_}
         d["device_name"] = s.device_name.decode("utf-8", "replace")
         return d
+
+    def stats(self):
+        """nsg_get_stats: forward passes and positions since creation (average batch = ratio)."""
+        b, n = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(self._lib.nsg_get_stats(self._h, ctypes.byref(b), ctypes.byref(n)))
+        return {"batches": b.value, "positions": n.value,
+                "average_batch": (n.value / b.value) if b.value else 0.0}
 
     def last_plan(self):
         """Launch plan of the most recent forward pass (nsg_get_last_plan)."""

@@ -371,11 +371,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
         // MX operand of lane (li, g): 32 fp8 bytes of chunk g>>1 (A / B buffer); g&1 ? lo bytes : hi bytes
         const int offp8 = (g >> 1) * G::kBuf + (4 + 2 * (g & 1) - g) * G::kPlane;
-#ifdef NSG_EXP_HOTW
-        const size_t rs = 0; // diagnostic: every weight record an L1 hit (results are wrong)
-#else
         const size_t rs = (size_t)nft * 64; // one record set
-#endif
         constexpr bool kStage = (KS == 1); // KS > 1: every chunk tile is resident, nothing is staged in the loop
         const int kpart = (KS > 1) ? wave % KS : 0; // this wave's share of the chunk pairs
         const int npairs = nkc / 2 / KS; // pairs this wave runs (the host pads the input channels to whole pairs)
@@ -473,13 +469,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     if (f == 0 && A.stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
                         A.stamps[2048 + kp * 32 + s] = __builtin_amdgcn_s_memtime();
 #endif
-#if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOWRITE)
                     if (kStage && q == kWriteStepA) { NSG_STAGE_WRITE((2 * kp + 2) & 3) }
                     if (kStage && q == kWriteStepB) { NSG_STAGE_WRITE((2 * kp + 3) & 3) }
-#endif
-#if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOBAR)
                     if (kStage && q == kBarStep) __syncthreads(); // publishes the two tiles written above
-#endif
                     // MX records: two sets.  X0 is requested at the top of the pair (set 0 is free once
                     // the previous pair's last MX slab is done), X_t+1 at the top of X_t.
                     const bool reqX = (s == 0) || (Q::isX(s) && Q::tap(s) + 1 < G::kTaps);
@@ -501,16 +493,12 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     }
                     const bool loadA = kStage && f == 0 && s >= kLoadSlabA && s < kLoadSlabA + kLoadSlabs;
                     const bool loadB = kStage && f == 0 && s >= kLoadSlabB && s < kLoadSlabB + kLoadSlabs;
-#if !defined(NSG_EXP_NOSTAGE) && !defined(NSG_EXP_NOLOAD)
                     if (loadA || loadB) {
 #pragma unroll
                         for (int k = s - (loadA ? kLoadSlabA : kLoadSlabB); k < G::kItems; k += kLoadSlabs)
                             st[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)(nextA + (loadB ? 1 : 0)) * 128);
                     }
-#endif
-#ifndef NSG_EXP_NOLDS
                     NSG_M8_REQ(q + kD, abuf, nbuf)
-#endif
                     const int slot = q % kWin;
                     if (Q::isX(s)) {
                         const i32x8 xb = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, aw[slot][0]),
@@ -928,11 +916,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         const unsigned char* resBase = A.res + tileOff;
         unsigned char* yBase = A.y + tileOff;
 
-#ifdef NSG_EXP_HOTRES
-#define NSG_RES_FRAG(F) 0 /* timing-only build: every residual fragment re-reads the first one (cache hits; results are wrong) */
-#else
 #define NSG_RES_FRAG(F) (F)
-#endif
         // Most of this wave's residual slice is requested up front (the main loop's operand registers
         // are dead), so the fragment pipeline below does not wait a global round trip per fragment.
         // (only the first kPreFrags fragments: with all eleven the epilogue spills; kernels capped at

@@ -12,6 +12,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -46,6 +48,41 @@ int fail(int code, const char* fmt, ...) {
             return fail(NSG_E_HIP, "%s failed: %s (%s:%d)", #call,                \
                         hipGetErrorString(e_), __FILE__, __LINE__);               \
     } while (0)
+
+// rocprofv3 markers (the reference has no profiler hooks; the build adds them): with
+// NSG_ROCTX=1 every forward pass brackets its phases -- H2D, planes, trunk, heads, D2H -- with roctx
+// ranges, resolved from librocprofiler-sdk-roctx.so at first use (no link-time dependency; without the
+// variable, or without the library, a range is two predictable branches).  The ranges mark where the
+// phase is ENQUEUED on the host; `rocprofv3 --marker-trace --kernel-trace` lines them up with the kernels.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("NSG_ROCTX");
+        if (!e || e[0] == '0') return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+struct Range {
+    bool on;
+    explicit Range(const char* name) : on(roctx().push != nullptr) {
+        if (on) roctx().push(name);
+    }
+    ~Range() {
+        if (on) roctx().pop();
+    }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
 
 struct DevBuf {
     void* p = nullptr;
@@ -230,6 +267,8 @@ struct nsg_evaluator {
 
     std::shared_ptr<NetWeights> W; // shared by the evaluators of one device (nsg_load_shared)
     int lastTrunkPrec = -1; // precision the most recent forward ran its trunk in
+    // host statistics (mcts::Statistics evaluationCount / batchSizeAccumulated, statistics.h:74-98)
+    uint64_t statBatches = 0, statPositions = 0;
     DevBuf stamps;           // diagnostic builds: per-layer, per-workgroup cycle stamps
     DevBuf trunkLayers;      // persistent-trunk layer list (stem + 2 per block)
     int trunkLayerCount = 0;
@@ -362,7 +401,11 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     const uint64_t* input = (const uint64_t*)ev->input.p + (size_t)off * ev->numChannels * 2;
     void* planes = act(ev->planes.p, (size_t)81 * ev->cpad);
     // feature planes (replaces cuda::extractBits, trt.cc:255-258)
-    NSG_HIP(nsg::launchExtractBitsAct(planes, input, count, ev->numChannels, ev->cpad, prec, s));
+    {
+        Range r("nsg.planes");
+        NSG_HIP(nsg::launchExtractBitsAct(planes, input, count, ev->numChannels, ev->cpad, prec, s));
+    }
+    Range trunkRange("nsg.trunk");
     // stem + residual trunk
     void* x = act(ev->act[0].p, (size_t)81 * ev->F);
     void* y = act(ev->act[1].p, (size_t)81 * ev->F);
@@ -392,6 +435,8 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     }
     if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
     if (off == 0) ev->trunkOut = x;
+    if (trunkRange.on) { roctx().pop(); trunkRange.on = false; }
+    Range headsRange("nsg.heads");
     // heads
     float* policy = (float*)ev->policy.p + (size_t)off * NSG_MOVE_INDEX_MAX;
     void* vfeat = act(ev->vfeat.p, (size_t)ev->fc1K);
@@ -409,6 +454,8 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
 
 int enqueueForward(nsg_evaluator* ev, size_t n) {
     const int B = (int)n;
+    ++ev->statBatches;
+    ev->statPositions += n;
     hipStream_t s = ev->stream;
     // the tile plan is chosen for the whole batch: all chains run concurrently
     nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount, ev->tuning);
@@ -614,9 +661,31 @@ extern "C" {
 const char* nsg_last_error(void) { return gLastError.c_str(); }
 const char* nsg_version(void) { return "nsg 0.1 (gfx950)"; }
 
+// The tuning variables are read when an evaluator is created; a value outside a variable's domain is an
+// error there, not a silent "automatic" (a typo must not turn an A/B run into A/A).
+static int checkTuningEnv() {
+    struct Var { const char* name; long lo, hi; const char* what; };
+    static const Var vars[] = {
+        {"NSG_CONV_NB", 1, 2, "boards per workgroup"}, {"NSG_CONV_NWAVES", 1, 4, "waves per workgroup"},
+        {"NSG_CONV_NFRAG", 1, 4, "fragments per wave (1, 2 or 4)"}, {"NSG_CONV_MSPLIT", 1, 2, "row split"},
+        {"NSG_CHAINS", 1, nsg_evaluator::kMaxChains, "half-batch chains"}, {"NSG_TRUNK_KERNEL", 0, 1, "persistent trunk"},
+        {"NSG_CHAIN_DELAY_US", -1, 1000000, "chain stagger"}, {"NSG_CHAIN_MIN_BATCH", 2, 65535, "smallest chained batch"},
+        {"NSG_KSPLIT4_MAX_BATCH", 0, 65535, "largest batch of the four-way K split"}, {"NSG_ROCTX", 0, 1, "profiler markers"}};
+    for (const Var& v : vars) {
+        const char* e = getenv(v.name);
+        if (!e) continue;
+        char* end = nullptr;
+        const long x = strtol(e, &end, 10);
+        const bool bad = end == e || *end != 0 || x < v.lo || x > v.hi || (!strcmp(v.name, "NSG_CONV_NFRAG") && x == 3);
+        if (bad) return fail(NSG_E_INVALID, "%s=%s: expected an integer in [%ld, %ld] (%s)", v.name, e, v.lo, v.hi, v.what);
+    }
+    return NSG_OK;
+}
+
 int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator** out) {
     if (!out) return fail(NSG_E_INVALID, "null out pointer");
     *out = nullptr;
+    if (int trc = checkTuningEnv()) return trc;
     if (batch_size_max <= 0 || batch_size_max > 65535 || num_channels <= 0 || num_channels > 1024)
         return fail(NSG_E_INVALID, "bad batch_size_max/num_channels");
     int count = 0;
@@ -884,10 +953,14 @@ int nsg_compute_nonblocking(nsg_evaluator* ev, const void* features, size_t batc
     if (hipStreamQuery(ev->stream) == hipErrorNotReady)
         return fail(NSG_E_BUSY, "computeNonBlocking called while a batch is in flight");
     // trt.cc:240-242
-    NSG_HIP(hipMemcpyAsync(ev->input.p, features,
-                           batch_size * ev->numChannels * NSG_BITBOARD_BYTES,
-                           hipMemcpyHostToDevice, ev->stream));
+    {
+        Range r("nsg.h2d");
+        NSG_HIP(hipMemcpyAsync(ev->input.p, features,
+                               batch_size * ev->numChannels * NSG_BITBOARD_BYTES,
+                               hipMemcpyHostToDevice, ev->stream));
+    }
     if ((rc = enqueueForward(ev, batch_size))) return rc;
+    Range d2h("nsg.d2h");
     // trt.cc:265-271
     NSG_HIP(hipMemcpyAsync(dst_policy, ev->policy.p, batch_size * NSG_MOVE_INDEX_MAX * sizeof(float),
                            hipMemcpyDeviceToHost, ev->stream));
@@ -1068,6 +1141,13 @@ int nsg_profile_read(nsg_evaluator* ev, double* trunk_ms_total, uint64_t* trunk_
     if (forwards) *forwards = ev->forwards;
     ev->trunkMs = ev->fwdMs = 0;
     ev->trunkLaunches = ev->forwards = 0;
+    return NSG_OK;
+}
+
+int nsg_get_stats(nsg_evaluator* ev, uint64_t* batches, uint64_t* positions) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    if (batches) *batches = ev->statBatches;
+    if (positions) *positions = ev->statPositions;
     return NSG_OK;
 }
 

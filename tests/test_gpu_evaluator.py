@@ -528,3 +528,38 @@ def test_half_batch_chains_bit_identical(nsg, oracle, monkeypatch, precision):
     np.testing.assert_array_equal(d, d1)
     idx = [0, batch // 2 - 1, batch // 2, batch // 2 + 1, batch - 1]
     check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), 2e-4)
+
+
+def test_host_stats_and_profiler_markers(nsg, tmp_path):
+    """nsg_get_stats (average batch = positions / batches, mcts::Statistics) and the roctx ranges:
+    with NSG_ROCTX=1 the marker library is resolved at first use and the outputs do not change."""
+    import subprocess
+    import sys
+    ev, _ = make(nsg, 2, 64, 16, seed=2)
+    bb = nsg.synth.random_batch(16, 86, seed=2)
+    assert ev.stats() == {"batches": 0, "positions": 0, "average_batch": 0.0}
+    ref = ev.compute_blocking(bb)
+    ev.compute_blocking(bb[:4])
+    ev.compute_blocking(bb[:1])
+    assert ev.stats() == {"batches": 3, "positions": 21, "average_batch": 7.0}
+    np.save(tmp_path / "ref.npy", ref[0])
+    code = ("import importlib, numpy as np, sys; nsg = importlib.import_module('nshogi-engine_amd');"
+            "ev = nsg.Evaluator(0, 16, 86); ev.load_memory(nsg.weights.to_blob(nsg.weights.make_random(2, 64, seed=2, bn='random')));"
+            "p, v, d = ev.compute_blocking(nsg.synth.random_batch(16, 86, seed=2));"
+            f"assert np.array_equal(p, np.load(r'{tmp_path / 'ref.npy'}')); print('markers ok')")
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root,
+                       env=dict(__import__("os").environ, NSG_ROCTX="1"))
+    assert r.returncode == 0 and "markers ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_tuning_variables_are_validated(nsg, monkeypatch):
+    """A tuning variable outside its domain is refused when the evaluator is created."""
+    for name, bad in (("NSG_CONV_NB", "3"), ("NSG_CONV_NFRAG", "3"), ("NSG_CHAINS", "two"), ("NSG_TRUNK_KERNEL", "yes"),
+                      ("NSG_CONV_MSPLIT", "0")):
+        monkeypatch.setenv(name, bad)
+        with pytest.raises(nsg.NsgError, match=name):
+            nsg.Evaluator(0, 4, 86)
+        monkeypatch.delenv(name)
+    monkeypatch.setenv("NSG_CONV_NB", "2")
+    nsg.Evaluator(0, 4, 86).close()
