@@ -220,6 +220,13 @@ typedef struct nsg_info {
     double flops_per_position;       /* SURVEY.md 8d formula             */
     double trunk_conv_flops_per_position; /* one F->F 3x3 conv: 2*81*9*F*F */
     char device_name[128];
+    /* Load-time estimate of the largest trunk activation (six standard deviations of the widest
+     * channel, second moments pushed through the folded layers) and whether an F16M8 evaluator
+     * found it outside the window its fixed-scale e4m3 copies cover (|x| < ~224): it then runs
+     * every batch on its F16X3 copy of the trunk (f32-equivalent, slower).  F16M6 carries one
+     * exponent per 32 channels and has no such window. */
+    double activation_bound_estimate;
+    int f16m8_window_fallback;
 } nsg_info;
 int nsg_get_info(nsg_evaluator* ev, nsg_info* info);
 

@@ -53,6 +53,8 @@ class _Info(ctypes.Structure):
         ("flops_per_position", ctypes.c_double),
         ("trunk_conv_flops_per_position", ctypes.c_double),
         ("device_name", ctypes.c_char * 128),
+        ("activation_bound_estimate", ctypes.c_double),
+        ("f16m8_window_fallback", ctypes.c_int),
     ]
 
 

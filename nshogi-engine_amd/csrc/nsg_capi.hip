@@ -132,6 +132,10 @@ struct NetWeights {
     int prec = 0;
     int F = 0, blocks = 0, vc = 0, vh = 0, cin = 0, cpad = 0, headsCout = 0, fc1K = 0;
     uint64_t params = 0;
+    // Estimated largest trunk activation (estimateActivationBound) and, for kF16m8, whether it leaves the
+    // window its fixed-scale e4m3 copies cover: then every batch runs the kF16x3 copy of the trunk.
+    double actBound = 0.0;
+    bool outsideM8Window = false;
     ConvLayer stem;
     std::vector<ConvLayer> conv1, conv2;
     // kF16m8 also holds the trunk in kF16x3 form: batches too small for full
@@ -216,6 +220,32 @@ void foldBn(const float* bn, int n, float eps, std::vector<double>* scale, std::
         (*scale)[i] = s;
         (*bias)[i] = (float)(b - m * s);
     }
+}
+
+// kF16m8's correction operands are e4m3 copies under FIXED scales (kernels.h): x_hi as it is and
+// x_lo * 2^12 must stay below 448, i.e. activations below ~224 (an f16 residual is at most 2^-11 of its
+// value); beyond that the copies clamp and the error drifts from 1e-4 towards plain f16's 1e-2
+// (profiles/r02/c_envelope_sweep.txt).  The bound is estimated from the WEIGHTS at load time by pushing
+// a second moment through the folded layers -- uncorrelated inputs: E[y_c^2] = |w'_c|^2 E[x^2] + b'_c^2,
+// a ReLU keeps half of it, a residual add sums the branches -- and taking six standard deviations of the
+// widest channel.  Crude (it ignores correlations) but monotone in what matters: BN gains, weight norms.
+struct MomentNet {
+    double x2 = 1.0; // second moment per input value entering the next layer
+    double peak = 0.0;
+};
+void pushConvMoment(const float* w, const double* scale, const float* bias, int cout, int cin, int taps,
+                    double in2, double* out2Max, double* out2Mean) {
+    double worst = 0.0, mean = 0.0;
+    for (int n = 0; n < cout; ++n) {
+        double ss = 0.0;
+        const float* wn = w + (size_t)n * cin * taps;
+        for (int k = 0; k < cin * taps; ++k) ss += (double)wn[k] * wn[k];
+        const double y2 = ss * scale[n] * scale[n] * in2 + (double)bias[n] * bias[n];
+        worst = std::max(worst, y2);
+        mean += y2;
+    }
+    *out2Max = worst;
+    *out2Mean = mean / cout;
 }
 
 struct Conv3Ctx { const float* w; const double* scale; int cin; };
@@ -390,7 +420,7 @@ __global__ void delayKernel(unsigned long long ticks) {
 int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& plan, hipStream_t s,
                  bool stampsOk, hipEvent_t trunkBegin = nullptr, hipEvent_t trunkEnd = nullptr) {
     // kF16m8 runs full tiles only; smaller launch plans use the kF16x3 copy of the trunk
-    const bool x3Fallback = (nsg::isMx(ev->prec) && plan.nfrag != 4);
+    const bool x3Fallback = nsg::isMx(ev->prec) && (plan.nfrag != 4 || ev->W->outsideM8Window);
     const int prec = x3Fallback ? (int)nsg::kF16x3 : ev->prec;
     const ConvLayer& stem = x3Fallback ? ev->W->stemX3 : ev->W->stem;
     const std::vector<ConvLayer>& conv1 = x3Fallback ? ev->W->conv1X3 : ev->W->conv1;
@@ -462,11 +492,13 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // kF16m8 keeps four image buffers in LDS (125 KB for two boards): a CU holds one two-board
     // workgroup, so where the channel count only allows two-wave workgroups (F = 384) one-board
     // tiles (74 KB) keep all four SIMDs busy with two workgroups per CU
-    if (nsg::isMx(ev->prec) && plan.nfrag == 4 && plan.nwaves <= 2 && ev->tuning.nb == 0) plan.nb = 1;
+    // (an F16M8 evaluator whose network left the fixed-scale window runs as kF16x3: none of the MX plans apply)
+    const bool mx = nsg::isMx(ev->prec) && !ev->W->outsideM8Window;
+    if (mx && plan.nfrag == 4 && plan.nwaves <= 2 && ev->tuning.nb == 0) plan.nb = 1;
     // Mid batches -- the engine's default batch of 128 and its benchmark's 60..159 -- run kF16m8
     // one-board tiles whose four waves are two row groups x two 64-channel groups (two workgroups per
     // board) wherever those fill more than half the CUs in one round of workgroups
-    if (nsg::isMx(ev->prec) && plan.nfrag != 4 && ev->F % 128 == 0 && ev->tuning.nfrag == 0 &&
+    if (mx && plan.nfrag != 4 && ev->F % 128 == 0 && ev->tuning.nfrag == 0 &&
         ev->tuning.msplit != 1) {
         const long cus = ev->prop.multiProcessorCount;
         const long wgM8 = (long)B * (ev->F / 128);
@@ -517,12 +549,13 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         else if (2 * tiles > cus && ev->chainDelayUs != 0 && ev->prec != nsg::kFp32) chains = std::min(ev->numChains, 2);
     }
     const bool stagger = oneRound && chains > 1;
-    if (ev->useTrunkKernel && nsg::canRunTrunk(ev->F, plan)) chains = 1;
+    const bool trunkKernel = ev->useTrunkKernel && !ev->W->outsideM8Window && nsg::canRunTrunk(ev->F, plan);
+    if (trunkKernel) chains = 1;
     const int per = ((B + chains - 1) / chains + 1) / 2 * 2; // boards per chain, whole 2-board tiles
     ev->lastPlan = plan;
     ev->lastChains = chains;
 
-    if (chains == 1 && ev->useTrunkKernel && nsg::canRunTrunk(ev->F, plan)) {
+    if (chains == 1 && trunkKernel) {
         // one persistent launch for all 2N+1 3x3 layers (measured slower; NSG_TRUNK_KERNEL=1)
         const int prec = ev->prec;
         NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, B, ev->numChannels,
@@ -862,6 +895,29 @@ int nsg_load_memory(nsg_evaluator* ev, const void* blob, size_t size) {
         Fc1Ctx c{nv.fc1W, nv.vc};
         if ((rc = uploadLayer(fc1Get, &c, 1, 81 * nv.vc, W->fc1K, nv.vh, nv.vh, nsg::headPrecision(prec), b1, &W->fc1))) return rc;
     }
+    {   // activation bound estimate (see pushConvMoment)
+        std::vector<double> sc;
+        std::vector<float> bi;
+        double worst = 0.0, mean = 0.0, peak2 = 0.0;
+        // feature planes are 0/1 (a handful of scalar planes in [0,1]): second moment <= the plane density, ~0.2
+        foldBn(nv.stemBn, nv.F, nv.eps, &sc, &bi);
+        pushConvMoment(nv.stemW, sc.data(), bi.data(), nv.F, nv.cin, 9, 0.2, &worst, &mean);
+        peak2 = worst;
+        double x2 = 0.5 * mean; // after the ReLU
+        for (int k = 0; k < nv.blocks; ++k) {
+            foldBn(nv.bn1[k], nv.F, nv.eps, &sc, &bi);
+            pushConvMoment(nv.w1[k], sc.data(), bi.data(), nv.F, nv.F, 9, x2, &worst, &mean);
+            peak2 = std::max(peak2, worst);
+            const double y2 = 0.5 * mean;
+            foldBn(nv.bn2[k], nv.F, nv.eps, &sc, &bi);
+            pushConvMoment(nv.w2[k], sc.data(), bi.data(), nv.F, nv.F, 9, y2, &worst, &mean);
+            peak2 = std::max(peak2, worst + x2); // the residual add
+            x2 = 0.5 * (mean + x2);
+        }
+        W->actBound = 6.0 * std::sqrt(peak2);
+        const char* off = getenv("NSG_M8_GUARD");
+        W->outsideM8Window = prec == nsg::kF16m8 && W->actBound > 224.0 && !(off && off[0] == '0');
+    }
     if ((rc = W->fc2W.alloc((size_t)2 * nv.vh * 4, false))) return rc;
     if ((rc = W->fc2B.alloc(8, false))) return rc;
     NSG_HIP(hipMemcpy(W->fc2W.p, nv.fc2W, (size_t)2 * nv.vh * 4, hipMemcpyHostToDevice));
@@ -889,6 +945,7 @@ int nsg_load_shared(nsg_evaluator* ev, nsg_evaluator* src) {
     W->gpu = ev->gpu; W->prec = S.prec;
     W->F = S.F; W->blocks = S.blocks; W->vc = S.vc; W->vh = S.vh; W->cin = S.cin; W->cpad = S.cpad;
     W->headsCout = S.headsCout; W->fc1K = S.fc1K; W->params = S.params;
+    W->actBound = S.actBound; W->outsideM8Window = S.outsideM8Window;
     auto copyBuf = [&](const DevBuf& s, DevBuf* d) -> int {
         if (!s.p) return NSG_OK;
         int r = d->alloc(s.bytes, false);
@@ -1192,6 +1249,8 @@ int nsg_get_info(nsg_evaluator* ev, nsg_info* info) {
     // stem + trunk + 1x1 policy (value/draw heads excluded)
     info->flops_per_position = 2.0 * 81 * 9 * C * F + N * 2 * (2.0 * 81 * 9 * F * F) + 2.0 * 81 * 27 * F;
     info->trunk_conv_flops_per_position = 2.0 * 81 * 9 * F * F;
+    info->activation_bound_estimate = ev->W ? ev->W->actBound : 0.0;
+    info->f16m8_window_fallback = (ev->W && ev->W->outsideM8Window) ? 1 : 0;
     // (boxes without the amdgpu.ids table report an empty marketing name: fall back to the ISA name)
     snprintf(info->device_name, sizeof(info->device_name), "%s", ev->prop.name[0] ? ev->prop.name : ev->prop.gcnArchName);
     return NSG_OK;

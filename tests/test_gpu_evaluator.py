@@ -221,12 +221,46 @@ def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch, ksplit, 
     np.testing.assert_array_equal(v2[::-1], v)
 
 
-def test_f16m8_extreme_magnitudes_stay_finite(nsg, oracle, monkeypatch):
-    """Activations far beyond the fp8 range of the correction operands (BN gamma 512 in the
-    stem: values in the thousands) and weights spanning many binades: the fixed-scale fp8
-    copies saturate instead of overflowing, so outputs stay finite and degrade no further
-    than plain f16 accuracy (the f16 main term is unaffected)."""
+def test_f16m8_window_guard(nsg, oracle, monkeypatch):
+    """The load-time guard of F16M8: a network whose estimated activations leave the window of the
+    fixed-scale e4m3 copies (here BN gamma 512 in the stem: values in the thousands) runs on the
+    evaluator's F16X3 copy of the trunk and keeps 1e-3; an ordinary network stays on the MX path."""
     monkeypatch.setenv("NSG_CONV_NFRAG", "4")
+    w = nsg.weights.make_random(2, 64, seed=22, bn="random")
+    ev = nsg.Evaluator(0, 8, 86, precision="f16m8")
+    ev.load_memory(nsg.weights.to_blob(w))
+    info = ev.info()
+    assert info["f16m8_window_fallback"] == 0 and 1.0 < info["activation_bound_estimate"] < 224.0
+    ev.compute_blocking(nsg.synth.random_batch(8, 86, seed=2))
+    assert ev.last_plan()["trunk_precision"] == "f16m8"
+    w["stem_bn"][0] *= 512.0
+    blob = nsg.weights.to_blob(w)
+    ev = nsg.Evaluator(0, 8, 86, precision="f16m8")
+    ev.load_memory(blob)
+    info = ev.info()
+    assert info["f16m8_window_fallback"] == 1 and info["activation_bound_estimate"] > 224.0
+    bb = nsg.synth.random_batch(8, 86, seed=2)
+    out = ev.compute_blocking(bb)
+    assert ev.last_plan()["trunk_precision"] == "f16x3"
+    ref = oracle.net(blob).evaluate(bb)
+    scale = max(1.0, float(np.abs(ref[0]).max()))
+    assert float(np.abs(out[0] - ref[0]).max()) <= 1e-4 * scale
+    # f16m6 needs no guard
+    ev6 = nsg.Evaluator(0, 8, 86, precision="f16m6")
+    ev6.load_memory(blob)
+    assert ev6.info()["f16m8_window_fallback"] == 0
+    out6 = ev6.compute_blocking(bb)
+    assert ev6.last_plan()["trunk_precision"] == "f16m6"
+    assert float(np.abs(out6[0] - ref[0]).max()) <= 1e-3 * scale
+
+
+def test_f16m8_extreme_magnitudes_stay_finite(nsg, oracle, monkeypatch):
+    """With the guard switched off (NSG_M8_GUARD=0): activations far beyond the fp8 range of the
+    correction operands (BN gamma 512 in the stem: values in the thousands) and weights spanning
+    many binades: the fixed-scale fp8 copies saturate instead of overflowing, so outputs stay finite
+    and degrade no further than plain f16 accuracy (the f16 main term is unaffected)."""
+    monkeypatch.setenv("NSG_CONV_NFRAG", "4")
+    monkeypatch.setenv("NSG_M8_GUARD", "0")
     w = nsg.weights.make_random(2, 64, seed=22, bn="random")
     rng = np.random.default_rng(4)
     w["b0_w1"] = (w["b0_w1"] * np.exp2(rng.integers(-10, 3, size=w["b0_w1"].shape[:1])).reshape(-1, 1, 1, 1)).astype(np.float32)
