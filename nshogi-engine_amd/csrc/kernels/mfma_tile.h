@@ -100,6 +100,40 @@ __device__ __forceinline__ int entryOfRow(int m) {
     }
 }
 
+// Zeroes the HALO entries of every image plane: the 24 leading entries, per board the rows y = -1 and
+// y = 9 and the column x = 9, and the padding behind the last board.  The interior entries are rewritten
+// by the staging of every chunk before anything reads them, so clearing the whole image (36 16-byte
+// stores per thread for the eight resident buffers of a K-split tile, 2.8k of its 9.7k prologue cycles)
+// is 2-3x the work needed.  Lane l owns halo entry l (+64, ...) and walks the planes: one address
+// computation per entry, then stores at a constant stride.
+template <class G>
+__device__ __forceinline__ void zeroHalo(unsigned char* smem, int tid) {
+    static_assert(G::kBoards, "board images only");
+    constexpr int kBoardsN = (G::kEntries - 24) / 110;
+    constexpr int kPlaneEntries = G::kPlane / 16;
+    constexpr int kHalo = 24 + 29 * kBoardsN + (kPlaneEntries - G::kEntries);
+    constexpr int kPlanes = G::kLds / G::kPlane;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int kWavesN = G::kThreads / 64;
+#pragma unroll
+    for (int h0 = 0; h0 < kHalo; h0 += 64) {
+        const int h = h0 + lane;
+        int e = h; // h < 24: the leading entries
+        if (h >= 24) {
+            const int q = h - 24, b = q / 29, r = q - b * 29;
+            const int within = r < 10 ? r : (r < 19 ? (r - 9) * 10 + 9 : 81 + r); // y = -1 | x = 9 of y = 0..8 | y = 9
+            e = b < kBoardsN ? 24 + b * 110 + within : G::kEntries + (q - 29 * kBoardsN);
+        }
+        if (h < kHalo) {
+            unsigned char* p = smem + e * 16 + wave * G::kPlane;
+#pragma unroll
+            for (int pl = 0; pl < (kPlanes + kWavesN - 1) / kWavesN; ++pl)
+                if (pl * kWavesN + wave < kPlanes)
+                    *reinterpret_cast<u32x4*>(p + (size_t)pl * kWavesN * G::kPlane) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+
 template <int PREC>
 __device__ __forceinline__ void mfmaSlab(f32x4& acc, const u32x4& w, const u32x4& a) {
     if constexpr (PREC == kFp32) {
@@ -285,6 +319,49 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     // kConv buffers are sized for whole workgroups; flat modes clamp rows.
     const size_t lastRow = G::kBoards ? ~(size_t)0 : (size_t)(A.totalRows - 1);
 
+    // staging: item k of this wave moves 16 rows x 4 chunks (16 B per lane)
+    size_t srcOff[G::kItems];
+    int dstOff[G::kItems];
+    bool itemOk[G::kItems];
+#pragma unroll
+    for (int k = 0; k < G::kItems; ++k) {
+        const int wid = wave + k * NWAVES;
+        const int m = (wid >> 1) * 16 + li;
+        itemOk[k] = (wid < 2 * G::kMF) && (m < G::kRows);
+        size_t grow = row0 + (itemOk[k] ? m : 0);
+        if (grow > lastRow) grow = lastRow;
+        srcOff[k] = grow * (size_t)A.kdim * ES + ((wid & 1) * 4 + g) * 16 + (size_t)kc0 * 128;
+    }
+    u32x4 st[G::kItems];
+    // K-split tiles (every chunk tile of the board resident): the tile loads go out FIRST, before the
+    // per-lane tables, the weight pointers and the first weight records are set up -- the prologue of these
+    // small-batch kernels is a third of their run time, and it used to spend 5k cycles before the last tile
+    // load was even issued (profiles/r01/h_stamps_f16m8_b64_ksplit4.txt).
+    constexpr bool kResident = isMx(PREC) && KS > 1;
+    constexpr int kResChunks = 8;
+    u32x4 stAll[kResident ? kResChunks : 1][G::kItems];
+    if constexpr (kResident) {
+#pragma unroll
+        for (int c = 0; c < kResChunks; ++c)
+#pragma unroll
+            for (int k = 0; k < G::kItems; ++k) {
+                stAll[c][k] = u32x4{0u, 0u, 0u, 0u};
+                if (c < nkc) stAll[c][k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)c * 128);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        NSG_STAMP(4); // (diagnostic builds) every tile load issued
+    }
+#pragma unroll
+    for (int k = 0; k < G::kItems; ++k) {
+        const int wid = wave + k * NWAVES;
+        const int c = (wid & 1) * 4 + g;
+        const int mm = itemOk[k] ? (wid >> 1) * 16 + li : 0;
+        // masked lanes store to their own trash slot behind both buffers (one shared slot made
+        // every masked store a 64-way same-address conflict that stalled the whole LDS): the store
+        // stays unconditional, so st[] stays in registers
+        dstOff[k] = itemOk[k] ? c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16 : G::kLds + lane * 16;
+    }
+
     // per-lane LDS read bases of the row fragments
     int abase[kMFw];
 #pragma unroll
@@ -298,27 +375,6 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         }
     }
 
-    // staging: item k of this wave moves 16 rows x 4 chunks (16 B per lane)
-    size_t srcOff[G::kItems];
-    int dstOff[G::kItems];
-    bool itemOk[G::kItems];
-#pragma unroll
-    for (int k = 0; k < G::kItems; ++k) {
-        const int wid = wave + k * NWAVES;
-        const int f = wid >> 1;
-        const int c = (wid & 1) * 4 + g;
-        const int m = f * 16 + li;
-        itemOk[k] = (wid < 2 * G::kMF) && (m < G::kRows);
-        const int mm = itemOk[k] ? m : 0;
-        size_t grow = row0 + mm;
-        if (grow > lastRow) grow = lastRow;
-        srcOff[k] = grow * (size_t)A.kdim * ES + c * 16 + (size_t)kc0 * 128;
-        // masked lanes store to their own trash slot behind both buffers (one shared slot made
-        // every masked store a 64-way same-address conflict that stalled the whole LDS): the store
-        // stays unconditional, so st[] stays in registers
-        dstOff[k] = itemOk[k] ? c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16 : G::kLds + lane * 16;
-    }
-    u32x4 st[G::kItems];
     // Pins every accumulator to an AGPR at the top of a K-chunk iteration.  Without it the
     // register allocator gives the loop-carried accumulators different registers at the
     // top and the bottom of the unrolled body and rotates all 176 of them through
@@ -392,11 +448,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         NSG_STAGE_LOAD(0)
 #pragma unroll
         for (int k = 0; k < G::kItems; ++k) st1[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + 128);
-        if (zeroLds) {
-            for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
-                reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
-            }
-        }
+        if (zeroLds) zeroHalo<G>(smem, tid);
         __syncthreads(); // zero fill done before staging writes
         NSG_STAGE_WRITE(0)
 #pragma unroll
@@ -404,22 +456,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? G::kBuf : 0) + dstOff[k]) = st1[k];
         __syncthreads();
         } else {
-            // every chunk of the board (at most eight) in one go
-            constexpr int kChunks = 8;
-            u32x4 stAll[kChunks][G::kItems];
-#pragma unroll
-            for (int c = 0; c < kChunks; ++c)
-#pragma unroll
-                for (int k = 0; k < G::kItems; ++k) {
-                    stAll[c][k] = u32x4{0u, 0u, 0u, 0u};
-                    if (c < nkc) stAll[c][k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)c * 128);
-                }
-            NSG_STAMP(4); // (diagnostic builds) setup done, every tile load issued
-            if (zeroLds) {
-                for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
-                    reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
-                }
-            }
+            // every chunk of the board (at most eight) was requested at the top of the kernel
+            constexpr int kChunks = kResChunks;
+            if (zeroLds) zeroHalo<G>(smem, tid);
             __syncthreads();
             NSG_STAMP(5); // image cleared; what follows waits for the tile loads
 #pragma unroll
@@ -605,12 +644,10 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     wp += (size_t)kLead * slabStride;
 
     NSG_STAGE_LOAD(0)
-    if (G::kBoards && zeroLds) {
-        // zero the LDS image (halo entries stay zero for the whole kernel) while the
+    if constexpr (G::kBoards) {
+        // zero the halo of the LDS image (it stays zero for the whole kernel) while the
         // first tile and the first weight slabs are in flight
-        for (int i = tid; i < G::kLds / 16; i += G::kThreads) {
-            reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
-        }
+        if (zeroLds) zeroHalo<G>(smem, tid);
     }
     if constexpr (G::kBoards) __syncthreads(); // zero fill done before staging writes
     NSG_STAGE_WRITE(0)
@@ -1015,12 +1052,17 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                         const uint32_t le[8] = {lh.s0, lh.s1, lh.s2, lh.s3, lh.s4, lh.s5, lh.s6, lh.s7};
                         const uint32_t lo8[8] = {lh.s8, lh.s9, lh.sa, lh.sb, lh.sc, lh.sd, lh.se, lh.sf};
                         const uint32_t hh[8] = {rp[0].x, rp[0].y, rp[0].z, rp[0].w, rp[1].x, rp[1].y, rp[1].z, rp[1].w};
+                        // hi + lo in f32 as ONE v_fma_mix_f32 per value (both f16 operands converted on the
+                        // fly; the opaque 1.0 keeps the fma from being folded into convert + add + add)
+                        typedef _Float16 f16x2r __attribute__((ext_vector_type(2)));
+                        float one = 1.0f;
+                        asm("" : "+v"(one));
 #pragma unroll
                         for (int d = 0; d < 8; ++d) { // dword d of my half = channels 2d, 2d+1
-                            const uint32_t l2 = odd ? lo8[d] : le[d];
-                            const uint32_t h2 = hh[d];
-                            v[2 * d] += f16BitsToF32((uint16_t)(h2 & 0xffffu)) + f16BitsToF32((uint16_t)(l2 & 0xffffu));
-                            v[2 * d + 1] += f16BitsToF32((uint16_t)(h2 >> 16)) + f16BitsToF32((uint16_t)(l2 >> 16));
+                            const f16x2r l2 = __builtin_bit_cast(f16x2r, odd ? lo8[d] : le[d]);
+                            const f16x2r h2 = __builtin_bit_cast(f16x2r, hh[d]);
+                            v[2 * d] += __builtin_fmaf((float)h2[0], one, (float)l2[0]);
+                            v[2 * d + 1] += __builtin_fmaf((float)h2[1], one, (float)l2[1]);
                         }
                     } else if constexpr (kM8) {
                         constexpr float kLoInv = 1.0f / (float)(1 << kM8LoShift);
@@ -1091,33 +1133,39 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                         typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
                         typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
                         typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
-                        float mh = 0.f, ml = 0.f;
                         // (scalars in plain arrays, vectors built by initialiser lists: element-wise writes to a
                         // 16-wide ext_vector in this loop compiled to compare/select chains, 2400 extra instructions)
+                        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                         uint32_t hpv[8], sa[8], sb[8];
+                        u16x2 mhp = {0, 0}, mlp = {0, 0}; // running maxima of |hi|, |lo| as f16 bit patterns (order-preserving)
+                        float mone = -1.0f;
+                        asm("" : "+v"(mone));
 #pragma unroll
                         for (int d = 0; d < 8; ++d) {
                             const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * d], floorV, 65000.f),
                                              __builtin_amdgcn_fmed3f(v[2 * d + 1], floorV, 65000.f)};
                             const f16x2 h = __builtin_convertvector(x, f16x2);
-                            const f32x2 hx = __builtin_convertvector(h, f32x2);
-                            const f32x2 lx = x - hx;
+                            // lo = x - hi as one v_fma_mix_f32 per value (hi converted on the fly)
+                            const f32x2 lx = {__builtin_fmaf((float)h[0], mone, x[0]), __builtin_fmaf((float)h[1], mone, x[1])};
                             const uint32_t hp = __builtin_bit_cast(uint32_t, h);
                             const uint32_t lp = __builtin_bit_cast(uint32_t, __builtin_convertvector(lx, f16x2));
                             hpv[d] = hp;
-                            mh = fmaxf(mh, fmaxf(fabsf(hx[0]), fabsf(hx[1])));
-                            ml = fmaxf(ml, fmaxf(fabsf(lx[0]), fabsf(lx[1])));
+                            const u16x2 ha = __builtin_bit_cast(u16x2, hp & 0x7fff7fffu), la = __builtin_bit_cast(u16x2, lp & 0x7fff7fffu);
+                            mhp = __builtin_elementwise_max(mhp, ha);
+                            mlp = __builtin_elementwise_max(mlp, la);
                             const u32x2v sw = __builtin_amdgcn_permlane16_swap(hp, lp, false, false);
                             sa[d] = sw.x;
                             sb[d] = sw.y;
                         }
+                        // f16 bit pattern -> E8M0: f16 exponent field e5 (bias 15) is the float exponent e5 + 112
+                        const uint32_t mhb = mhp[0] > mhp[1] ? mhp[0] : mhp[1], mlb = mlp[0] > mlp[1] ? mlp[0] : mlp[1];
                         op[0] = u32x4{hpv[0], hpv[1], hpv[2], hpv[3]};
                         op[1] = u32x4{hpv[4], hpv[5], hpv[6], hpv[7]};
                         const u32x16 src = {sa[0], sa[1], sa[2], sa[3], sa[4], sa[5], sa[6], sa[7],
                                             sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], sb[6], sb[7]};
-                        const u32x2v mm = __builtin_amdgcn_permlane16_swap(__float_as_uint(mh), __float_as_uint(ml), false, false);
-                        const uint32_t ef = (mm.x > mm.y ? mm.x : mm.y) >> 23; // non-negative floats order like their bits
-                        const uint32_t e8 = ef > 3u ? ef - 2u : 1u;
+                        const u32x2v mm = __builtin_amdgcn_permlane16_swap(mhb, mlb, false, false);
+                        const uint32_t e5 = (mm.x > mm.y ? mm.x : mm.y) >> 10; // biased f16 exponent of my block's maximum
+                        const uint32_t e8 = e5 + 110u;                           // (e5 + 112) - 2; e5 = 0 (zero / subnormal block): 2^-17
                         u32x6 blk;
                         const float sc = __uint_as_float(e8 << 23);
                         asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(blk) : "v"(src), "v"(sc));
