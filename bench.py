@@ -181,7 +181,7 @@ def quick_rate(nsg, local_rank, blob, bb, B, precision, steps=5):
 SELFPLAY_BIN = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "selfplay", "selfplay")
 
 
-def selfplay_leg(weights_path, gpu, seconds, threads, precision, playouts=800, games_per_group=256, workers=1):
+def selfplay_leg(weights_path, gpu, seconds, threads, precision, playouts=800, games_per_group=256, workers=1, solvers=0):
     """BASELINE metric #2 on this rank's GPU: the self-play driver (csrc/selfplay) with
     the reference's option names/values of config 4 (--num-playouts 800, batch = games per
     group).  games/sec = finished games / elapsed (saveworker.cc:135-137).  Never raises: a rank
@@ -190,7 +190,8 @@ def selfplay_leg(weights_path, gpu, seconds, threads, precision, playouts=800, g
     prec = {"fp32": 0, "fp16": 1, "bf16": 2, "f16x3": 3, "f16m8": 4, "f16m6": 5}[precision]
     try:
         r = subprocess.run([SELFPLAY_BIN, "--executor", "hip", "--weights", weights_path, "--gpu", str(gpu),
-                            "--threads", str(threads), "--workers", str(workers), "--games-per-group", str(games_per_group),
+                            "--threads", str(threads), "--workers", str(workers), "--solver-threads", str(solvers),
+                            "--games-per-group", str(games_per_group),
                             "--playouts", str(playouts), "--seconds", str(seconds), "--seed", "1",
                             "--precision", str(prec)], capture_output=True, text=True, timeout=seconds * 3 + 300)
         if r.returncode != 0:
@@ -231,6 +232,8 @@ def main():
     # host threads advancing the engine's games between two batches: one keeps up in the opening, two to
     # three are needed once positions get busy (profiles/r02/a_selfplay_shape_workers.txt)
     ap.add_argument("--selfplay-workers", type=int, default=3)
+    # threads that run the df-pn mate solver of judge (100 000 nodes, worker.cc:516) off the search path
+    ap.add_argument("--selfplay-solver-threads", type=int, default=4)
     ap.add_argument("--selfplay-games-per-group", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
@@ -328,7 +331,8 @@ def main():
         barrier()
         ev.close()  # free this process's evaluator before the self-play process allocates its own
         mine = selfplay_leg(wpath, local_rank, args.selfplay_seconds, args.selfplay_threads, args.precision,
-                            games_per_group=args.selfplay_games_per_group, workers=args.selfplay_workers)
+                            games_per_group=args.selfplay_games_per_group, workers=args.selfplay_workers,
+                            solvers=args.selfplay_solver_threads)
         try:
             os.remove(wpath)
         except OSError:
@@ -348,6 +352,7 @@ def main():
             sp = dict(tot, **{k: mine[k] for k in ("avg_batch", "cache_hit_ratio", "avg_game_length", "playouts_per_move",
                                                    "seconds", "window_seconds") if k in mine},
                       threads_per_gpu=mine.get("threads"), workers_per_thread=mine.get("workers"),
+                      solver_threads=mine.get("solver_threads"),
                       note="AlphaZero-mode self-play from startpos on this build's own shogi core; synthetic "
                            "(untrained) weights, so games end early by repetition: games/sec is a plumbing number, "
                            "evals/playouts per sec are the load.  games_per_sec = finished / elapsed from a cold "

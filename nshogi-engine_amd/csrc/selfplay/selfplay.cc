@@ -86,6 +86,10 @@ class Game {
             case Phase::Backpropagation: backpropagate(); break;
             case Phase::Transition: transition(); break;
             case Phase::Judging: judge(); break;
+            case Phase::SolverWait:
+                if (!SolverDone.load(std::memory_order_acquire)) return false; // the mate solver still has this position
+                afterSolver(SolverMove, SolverNodes);
+                break;
             }
         }
         return false;
@@ -105,7 +109,17 @@ class Game {
     }
 
  private:
-    enum class Phase { RootPreparation, LeafSelection, LeafTerminalChecking, Evaluation, Backpropagation, Transition, Judging };
+    enum class Phase { RootPreparation, LeafSelection, LeafTerminalChecking, Evaluation, Backpropagation, Transition, Judging, SolverWait };
+
+ public:
+    // solver-pool side: the game is parked in SolverWait, nobody else touches S meanwhile
+    void solveNow(shogi::DfpnSolver& Solver) {
+        SolverMove = Solver.solve(S, Eng->Opt.DfpnNodes);
+        SolverNodes = Solver.nodes();
+        SolverDone.store(true, std::memory_order_release);
+    }
+
+ private:
 
     Node* newNode(Node* Parent) {
         Node* N = new (Tree.alloc(sizeof(Node))) Node();
@@ -465,19 +479,33 @@ class Game {
         if (L.size() == 0) return finish(~S.sideToMove());
         if (S.ply() >= Config.MaxPly) return finish(shogi::NoColor);
         if (Eng->Opt.DfpnNodes) { // worker.cc:516-524: a proven mate ends the game with the mating move played
-            const Move Mate = Ctx->Solver.solve(S, Eng->Opt.DfpnNodes);
-            Ctx->St.DfpnNodes += Ctx->Solver.nodes();
-            if (!Mate.isNone()) {
-                const Color Winner = S.sideToMove();
-                FullSearch = true; // pushDidFullSearch(true)
-                playMove(Mate);
-                ++Ctx->St.DfpnMates;
-                return finish(Winner);
+            if (Eng->Opt.SolverThreads > 0) {
+                SolverDone.store(false, std::memory_order_relaxed);
+                Ph = Phase::SolverWait;
+                Eng->submitSolve(this);
+                return;
             }
+            const Move Mate = Ctx->Solver.solve(S, Eng->Opt.DfpnNodes);
+            return afterSolver(Mate, Ctx->Solver.nodes());
         }
         Ph = Phase::RootPreparation;
     }
 
+    void afterSolver(Move Mate, uint64_t Nodes) {
+        Ctx->St.DfpnNodes += Nodes;
+        if (!Mate.isNone()) {
+            const Color Winner = S.sideToMove();
+            FullSearch = true; // pushDidFullSearch(true)
+            playMove(Mate);
+            ++Ctx->St.DfpnMates;
+            return finish(Winner);
+        }
+        Ph = Phase::RootPreparation;
+    }
+
+    std::atomic<bool> SolverDone{false};
+    Move SolverMove;
+    uint64_t SolverNodes = 0;
     Engine* Eng;
     Engine::WorkerCtx* Ctx; // the worker that owns this game slot
     uint64_t GameId; // of the game being played: slot + k * Stride
@@ -541,10 +569,41 @@ Engine::Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& O, uint6
                 EngineIndex * Mine + (uint64_t)G * (uint64_t)Opt.GamesPerGroup + (uint64_t)I, Stride));
     }
     for (int W = 1; W < Opt.Workers; ++W) Pool.emplace_back([this, W]() { workerLoop(W); });
+    for (int T = 0; T < Opt.SolverThreads; ++T) Solvers.emplace_back([this]() { solverLoop(); });
+}
+
+void Engine::submitSolve(Game* G) {
+    {
+        std::lock_guard<std::mutex> Lock(SolveMutex);
+        SolveQueue.push_back(G);
+    }
+    SolveCV.notify_one();
+}
+
+void Engine::solverLoop() {
+    shogi::DfpnSolver Solver;
+    for (;;) {
+        Game* G;
+        {
+            std::unique_lock<std::mutex> Lock(SolveMutex);
+            SolveCV.wait(Lock, [this]() { return SolveQuit || !SolveQueue.empty(); });
+            if (SolveQueue.empty()) return;
+            G = SolveQueue.front();
+            SolveQueue.pop_front();
+        }
+        G->solveNow(Solver);
+    }
 }
 
 Engine::~Engine() {
     drain();
+    {
+        std::lock_guard<std::mutex> Lock(SolveMutex);
+        SolveQuit = true;
+        SolveQueue.clear(); // games parked on the solver are simply never resumed
+    }
+    SolveCV.notify_all();
+    for (auto& T : Solvers) T.join();
     Quit.store(true, std::memory_order_release);
     Epoch.fetch_add(1, std::memory_order_release);
     for (auto& T : Pool) T.join();

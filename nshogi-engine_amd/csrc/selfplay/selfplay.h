@@ -44,7 +44,10 @@
 #include <nshogi_engine_amd/infer/infer.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <mutex>
 #include <memory>
 #include <functional>
 #include <random>
@@ -67,6 +70,13 @@ struct Options {
     bool RandomDrawValue = true; // worker.cc:142-150
     uint64_t TotalSlots = 0;     // concurrent games of the whole run (all engines); 0 = this engine's own
     int Workers = 1;             // host threads that advance one engine's games between two batches (fork-join)
+    // The df-pn call in judge (worker.cc:516-524) can take its whole node budget -- 0.3 s at 100 000 nodes -- and
+    // inside a fork-join step that stalls every other game of the engine.  With SolverThreads > 0 a game hands
+    // its position to a pool of solver threads and simply contributes no leaf until the answer is there (in
+    // the reference the call blocks one of many search workers, and the other frames go on).  The games
+    // themselves are unchanged (own RNG, own tree); what changes with timing is which games share a batch
+    // and which have finished when the run stops, so run-to-run digests are only reproducible at 0.
+    int SolverThreads = 0;
     uint64_t DfpnNodes = 100000; // node budget of the df-pn mate solver run after every move (worker.cc:516); 0 = off
     bool MateSearch = true;      // mate-in-3 search by checks at every non-root leaf (worker.cc:349-358)
 };
@@ -150,6 +160,8 @@ class Engine {
     void apply(Group& G);
     void parallelFor(const std::function<void(int)>& Fn); // Fn(worker) on every worker, caller = worker 0
     void workerLoop(int W);
+    void solverLoop();
+    void submitSolve(Game* G);
     int ownerOf(std::size_t GameIndex, std::size_t Games) const;
 
     Options Opt;
@@ -162,6 +174,11 @@ class Engine {
     std::atomic<uint64_t> Epoch{0};
     std::atomic<int> Done{0};
     std::atomic<bool> Quit{false};
+    std::vector<std::thread> Solvers;
+    std::mutex SolveMutex;
+    std::condition_variable SolveCV;
+    std::deque<Game*> SolveQueue;
+    bool SolveQuit = false;
     std::atomic<uint64_t> PubFinished{0}, PubEvaluations{0}, PubMoves{0};
     std::unique_ptr<Group> Groups[2];
     EvalCache* Cache = nullptr;

@@ -19,7 +19,8 @@
 // usage: selfplay [--executor hip|random|zero] [--weights model.onnx|file.nsgw] [--gpu 0] [--num-gpus 1]
 //                 [--threads 2] [--workers 1] [--games-per-group 256] [--playouts 800]
 //                 (--threads: engines per GPU, each with its own two batches in flight; --workers: host
-//                  threads per engine that advance its games between two batches)
+//                  threads per engine that advance its games between two batches; --solver-threads: threads per
+//                  engine that run the df-pn call of judge off the search path, 0 = inline)
 //                 [--seconds 30] [--max-games 0] [--seed 0] [--precision 3] [--mate-search 1] [--dfpn-nodes 100000]
 //                 [--evaluation-cache-memory-size 1024]   (MB per GPU shard, split over its caches; 0 = no cache)
 //                 [--share-evaluation-cache 0]
@@ -65,6 +66,7 @@ int main(int Argc, char* Argv[]) {
         else if (K == "--num-gpus") NumGpus = std::stoi(V);
         else if (K == "--threads") Threads = std::stoi(V);
         else if (K == "--workers" || K == "--num-search-workers") Opt.Workers = std::stoi(V);
+        else if (K == "--solver-threads") Opt.SolverThreads = std::stoi(V);
         else if (K == "--games-per-group") Opt.GamesPerGroup = std::stoi(V);
         else if (K == "--playouts" || K == "--num-playouts") Opt.NumPlayouts = std::stoi(V);
         else if (K == "--seconds") Seconds = std::stod(V);
@@ -181,7 +183,7 @@ int main(int Argc, char* Argv[]) {
         break;
     }
     const double Fin = (double)S.finished();
-    std::cout << "{\"executor\": \"" << Executor << "\", \"num_gpus\": " << NumGpus << ", \"threads\": " << Threads << ", \"workers\": " << Opt.Workers
+    std::cout << "{\"executor\": \"" << Executor << "\", \"num_gpus\": " << NumGpus << ", \"threads\": " << Threads << ", \"workers\": " << Opt.Workers << ", \"solver_threads\": " << Opt.SolverThreads
               << ", \"games_per_group\": " << Opt.GamesPerGroup << ", \"concurrent_games\": " << Opt.TotalSlots
               << ", \"playouts_per_move\": " << Opt.NumPlayouts << ", \"seconds\": " << Dt
               << ", \"games_finished\": " << S.finished() << ", \"games_per_sec\": " << Fin / Dt

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 os.environ["NSG_LIB"] = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "libnsg_diag.so")
 nsg = importlib.import_module("nshogi-engine_amd")
 blocks, ch, B = 20, 256, 512
-ev = nsg.Evaluator(0, B, 86, precision="f16m8")
+ev = nsg.Evaluator(0, B, 86, precision=(sys.argv[1] if len(sys.argv) > 1 else "f16m8"))
 ev.load_memory(nsg.weights.to_blob(nsg.weights.make_random(blocks, ch, seed=0)))
 lib = nsg.load_library()
 lib.nsg_debug_stamps_enable.argtypes = [ctypes.c_void_p]; lib.nsg_debug_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

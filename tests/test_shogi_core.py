@@ -188,22 +188,24 @@ def test_selfplay_games_do_not_depend_on_grouping(tmp_path):
     executor whose outputs do not depend on batch composition (infer::Zero here) every game is the
     same game however the N slots are spread: 1 thread x 2 groups x 6, 2 threads x 2 x 3 sharing one
     evaluation cache, or two GPU shards (--num-gpus 2; the CPU executors stand in for the devices)
-    x 1 thread x 2 x 3, or one engine whose games are advanced by three host threads (--workers 3)."""
+    x 1 thread x 2 x 3, one engine whose games are advanced by three host threads (--workers 3), or with
+    the df-pn call of judge handed to a pool of solver threads (--solver-threads 2)."""
     base = ["--executor", "zero", "--playouts", "40", "--seed", "3", "--dfpn-nodes", "2000", "--max-games", "10"]
     logs = []
     for i, shape in enumerate((["--threads", "1", "--games-per-group", "6"],
                                ["--threads", "2", "--games-per-group", "3", "--share-evaluation-cache", "1"],
                                ["--num-gpus", "2", "--threads", "1", "--games-per-group", "3"],
-                               ["--threads", "1", "--workers", "3", "--games-per-group", "6"])):
+                               ["--threads", "1", "--workers", "3", "--games-per-group", "6"],
+                               ["--threads", "1", "--workers", "2", "--solver-threads", "2", "--games-per-group", "6"])):
         path = tmp_path / f"g{i}.log"
         out = json.loads(run("selfplay", *base, *shape, "--game-log", path))
         assert out["concurrent_games"] == 12 and out["games_finished"] >= 10
         logs.append(_game_log(path))
     assert json.loads(run("selfplay", *base, "--num-gpus", "2", "--threads", "1", "--games-per-group", "3"))["num_gpus"] == 2
-    common = set(logs[0]) & set(logs[1]) & set(logs[2]) & set(logs[3])
+    common = set(logs[0]) & set(logs[1]) & set(logs[2]) & set(logs[3]) & set(logs[4])
     assert len(common) >= 6
     for gid in common:
-        assert logs[0][gid] == logs[1][gid] == logs[2][gid] == logs[3][gid], gid
+        assert logs[0][gid] == logs[1][gid] == logs[2][gid] == logs[3][gid] == logs[4][gid], gid
     # the per-GPU shards both worked
     out = json.loads(run("selfplay", *base, "--num-gpus", "2", "--threads", "2", "--games-per-group", "2"))
     assert len(out["evals_per_sec_by_gpu"]) == 2 and all(x > 0 for x in out["evals_per_sec_by_gpu"])
