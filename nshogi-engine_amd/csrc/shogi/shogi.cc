@@ -649,13 +649,57 @@ bool State::givesCheck(Move M) const {
     return false;
 }
 
+// A square the king of `Defender` can step to safely (empty or enemy-occupied, not attacked once the king
+// has left its square), or -1.  The cheap way to see that a check is not mate: most checks leave one.
+int State::kingFlight(Color Defender) const {
+    const int K = KingSq[Defender];
+    const int F0 = fileOf(K), R0 = rankOf(K);
+    for (int D = 0; D < 8; ++D) {
+        const int F = F0 + kDF[D], R = R0 + kDR[D];
+        if (!onBoard(F, R)) continue;
+        const int Sq = makeSquare(F, R);
+        const Piece P = Board[Sq];
+        if (P && colorOf(P) == Defender) continue;
+        if (!attackedWithout(Sq, ~Defender, K, -1)) return Sq;
+    }
+    return -1;
+}
+
+// Mate in one for the side to move, without the full legal move list: pseudo-legal moves, kept only if
+// they give check (exact, no move made), and only those are played -- the own king must then be safe
+// (legality), the opponent's king without a flight square, and the opponent without any reply.  A mate
+// by a dropped pawn is not a legal move.
+Move State::findMateInOneQuick() {
+    MoveList Pseudo;
+    generatePseudo(Pseudo);
+    const Color Us = Side;
+    for (const Move& M : Pseudo) {
+        if (!givesCheck(M)) continue;
+        if (M.isDrop() && M.moved() == Pawn) continue;
+        doMove(M);
+        bool Mate = false;
+        if (!isAttacked(KingSq[Us], ~Us) && kingFlight(~Us) < 0) { // a legal move, and the king cannot just step away
+            MoveList Replies;
+            generateLegalMoves(Replies);
+            Mate = Replies.size() == 0;
+        }
+        undoMove();
+        if (Mate) return M;
+    }
+    return Move();
+}
+
 Move State::findMate(int Depth, bool Prefilter, const MoveList* Legal) {
     if (Depth < 1) return Move();
     MoveList Own;
     if (!Legal) generateLegalMoves(Own);
     const MoveList& Moves = Legal ? *Legal : Own;
-    // checking moves first pass: mate in one; second pass (Depth >= 3): every reply refuted
+    // First pass over the checking moves: mate in one.  A check that leaves the king a flight square is
+    // not mate, and its replies are not generated yet (Flight[] remembers the square).  Second pass
+    // (Depth >= 3): a check mates in three if every reply runs into a mate in one -- the king's step to the
+    // remembered flight square is tried first, and only a check that survives it gets its full reply list.
     Move Checks[600];
+    int8_t Flight[600];
     int NumChecks = 0;
     for (const Move& M : Moves) {
         if (Prefilter && !givesCheck(M)) continue;
@@ -664,25 +708,39 @@ Move State::findMate(int Depth, bool Prefilter, const MoveList* Legal) {
             undoMove();
             continue;
         }
-        MoveList Replies;
-        generateLegalMoves(Replies);
+        const int Fl = Prefilter ? kingFlight(Side) : -1;
+        int NumReplies = 1;
+        if (Fl < 0) {
+            MoveList Replies;
+            generateLegalMoves(Replies);
+            NumReplies = Replies.size();
+        }
         undoMove();
-        if (Replies.size() == 0) return M; // drop-pawn mate is not a legal move, so M is a real mate
+        if (NumReplies == 0) return M; // drop-pawn mate is not a legal move, so M is a real mate
+        Flight[NumChecks] = (int8_t)Fl;
         Checks[NumChecks++] = M;
     }
     if (Depth < 3) return Move();
     for (int I = 0; I < NumChecks; ++I) {
         doMove(Checks[I]);
-        MoveList Replies;
-        generateLegalMoves(Replies);
         bool AllMated = true;
-        for (const Move& R : Replies) {
-            doMove(R);
-            const bool Mated = !findMate(1, Prefilter).isNone();
+        if (Flight[I] >= 0) { // the cheapest refutation candidate: the king steps away
+            const int K = KingSq[Side];
+            doMove(Move::make(K, Flight[I], false, King, typeOf(Board[Flight[I]])));
+            AllMated = !findMateInOneQuick().isNone();
             undoMove();
-            if (!Mated) {
-                AllMated = false;
-                break;
+        }
+        if (AllMated) {
+            MoveList Replies;
+            generateLegalMoves(Replies);
+            for (const Move& R : Replies) {
+                doMove(R);
+                const bool Mated = Prefilter ? !findMateInOneQuick().isNone() : !findMate(1, false).isNone();
+                undoMove();
+                if (!Mated) {
+                    AllMated = false;
+                    break;
+                }
             }
         }
         undoMove();

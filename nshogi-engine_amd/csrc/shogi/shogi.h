@@ -127,6 +127,9 @@ class State {
     // plies (1 or 3) against every defence, or a none move.  Prefilter = false tests every
     // legal move for check (slow reference for the tests).
     Move findMate(int Depth, bool Prefilter = true, const MoveList* Legal = nullptr); // Legal: the position's legal moves, if already generated
+    // Mate in one from pseudo-legal checking moves only (the inner test of findMate(3)).
+    Move findMateInOneQuick();
+    int kingFlight(Color Defender) const;
     // Does this legal move of the side to move give check (directly or by discovery)?  Exact,
     // from the current position, without making the move.
     bool givesCheck(Move M) const;
