@@ -92,7 +92,8 @@ def pmc_summary(args, B):
 
 def _conv_rows(d):
     # full-tile trunk conv: tileKernel<PREC, MODE 0 conv, 2 boards, 4 fragments, 4 waves, residual?>
-    return [c for name, c in (d or {}).items() if "tileKernel" in name and ", 0, 2, 4, 4," in name]
+    rows = [c for name, c in (d or {}).items() if "trunkKernel" in name]
+    return rows or [c for name, c in (d or {}).items() if "tileKernel" in name and ", 0, 2, 4, 4," in name]
 
 
 def conv_traffic_bytes(d):
@@ -367,7 +368,13 @@ def main():
         evals = B * args.steps * world
         value = evals / dt
         flops_pos = info["flops_per_position"]
+        # The timed launches are the 2N F->F convolutions of a forward -- or, when the evaluator ran the whole
+        # trunk as ONE persistent launch (f16m6 at this batch: nsg.h, nsg_profile_read), that launch: stem + 2N convs.
+        persistent = prof["trunk_launches"] == prof["forwards"]
+        stem_flops = 2.0 * 81 * 9 * 86 * channels
         conv_flops_launch = info["trunk_conv_flops_per_position"] * B
+        if persistent:
+            conv_flops_launch = (stem_flops + 2 * blocks * info["trunk_conv_flops_per_position"]) * B
         conv_ms = prof["trunk_ms_total"] / max(prof["trunk_launches"], 1)
         achieved = conv_flops_launch / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
@@ -394,7 +401,8 @@ def main():
                                             f"measured by this run)" if pmc_file else None),
                          "mfma_pipe_busy_frac_pmc": conv_mfma_busy(pmc),
                          "mfma_flops_executed_per_algorithmic_flop": MFMA_UNITS[args.precision],
-                         "kernel": "tileKernel<kConv> (3x3 conv F->F, bias+residual+ReLU fused)",
+                         "kernel": ("trunkKernel (ONE persistent launch: stem + %d x 3x3 conv F->F, bias+residual+ReLU fused)" % (2 * blocks))
+                                   if persistent else "tileKernel<kConv> (3x3 conv F->F, bias+residual+ReLU fused)",
                          "avg_launch_ms": conv_ms, "launches_timed": prof["trunk_launches"],
                          "algorithmic_flops_per_launch": conv_flops_launch},
             "whole_net_tflops": value / world * flops_pos / 1e12,
@@ -406,6 +414,7 @@ def main():
             out["sustained_evals_per_sec"] = sustained["evals_per_sec"]
             sc = sustained["conv_avg_launch_ms"]
             sustained["conv_frac_of_peak"] = conv_flops_launch / (sc * 1e-3) / 1e12 / peak if sc > 0 else None
+            sustained["persistent_trunk_launch"] = bool(persistent)
             out["sustained"] = sustained
         if sp is not None:
             out["selfplay"] = sp

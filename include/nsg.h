@@ -198,7 +198,9 @@ int nsg_download_trunk(nsg_evaluator* ev, size_t batch_size, float* dst);
 /* HIP-event timing of the dominant kernel (the F->F 3x3 residual
  * convolution) on the evaluator's own stream.  While enabled, every forward
  * brackets its run of trunk-conv launches with two events; nsg_profile_read
- * synchronises and accumulates.  *launches counts kernel launches. */
+ * synchronises and accumulates.  *launches counts kernel launches: 2 x blocks
+ * per forward, or ONE per forward when the whole trunk (stem + 2 x blocks
+ * convolutions) ran as one persistent launch (*trunk_launches == *forwards). */
 int nsg_profile_enable(nsg_evaluator* ev, int enable);
 int nsg_profile_read(nsg_evaluator* ev, double* trunk_ms_total,
                      uint64_t* trunk_launches, double* forward_ms_total,

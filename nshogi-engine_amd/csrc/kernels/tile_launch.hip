@@ -129,7 +129,8 @@ void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfra
 }
 
 bool canRunTrunk(int cout, const ConvPlan& plan) {
-    return plan.nfrag == kNfrag && cout == plan.nwaves * 64 && (plan.nwaves == 4 || plan.nwaves == 3);
+    return plan.nfrag == kNfrag && plan.msplit == 1 && plan.ksplit == 1 && cout == plan.nwaves * 64 &&
+           (plan.nwaves == 4 || plan.nwaves == 3);
 }
 
 hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,

@@ -352,16 +352,24 @@ def test_staggered_chains_bit_identical(nsg, monkeypatch, precision):
             np.testing.assert_array_equal(x, y)
 
 
-def test_f16m8_persistent_trunk_kernel_bit_identical(nsg, monkeypatch):
-    """NSG_TRUNK_KERNEL=1: all 3x3 layers in one launch (a workgroup owns its boards through
-    every layer, no grid barrier).  Same arithmetic, so bit-identical to per-layer launches."""
+@pytest.mark.parametrize("mx", ["f16m8", "f16m6"])
+def test_f16m8_persistent_trunk_kernel_bit_identical(nsg, monkeypatch, mx):
+    """One launch for all 3x3 layers (a workgroup owns its boards through every layer, no grid
+    barrier; automatic for f16m6 when every tile is resident at once, NSG_TRUNK_KERNEL=0 / 1 forces it
+    off / on).  Same arithmetic, so bit-identical to per-layer launches."""
     bb = nsg.synth.random_batch(300, 86, seed=79)
-    ev, _ = make(nsg, 3, 256, 300, precision="f16m8", seed=34)
+    monkeypatch.setenv("NSG_TRUNK_KERNEL", "0")
+    ev, _ = make(nsg, 3, 256, 300, precision=mx, seed=34)
     p, v, d = ev.compute_blocking(bb)
     monkeypatch.setenv("NSG_TRUNK_KERNEL", "1")
-    ev1, _ = make(nsg, 3, 256, 300, precision="f16m8", seed=34)
+    ev1, _ = make(nsg, 3, 256, 300, precision=mx, seed=34)
     p1, v1, d1 = ev1.compute_blocking(bb)
-    assert ev1.last_plan()["trunk_precision"] == "f16m8"
+    assert ev1.last_plan()["trunk_precision"] == mx
+    monkeypatch.delenv("NSG_TRUNK_KERNEL")
+    ev2, _ = make(nsg, 3, 256, 300, precision=mx, seed=34)  # automatic
+    p2, v2, d2 = ev2.compute_blocking(bb)
+    np.testing.assert_array_equal(p, p2)
+    np.testing.assert_array_equal(v, v2)
     np.testing.assert_array_equal(p, p1)
     np.testing.assert_array_equal(v, v1)
     np.testing.assert_array_equal(d, d1)
@@ -597,3 +605,29 @@ def test_tuning_variables_are_validated(nsg, monkeypatch):
         monkeypatch.delenv(name)
     monkeypatch.setenv("NSG_CONV_NB", "2")
     nsg.Evaluator(0, 4, 86).close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16m6"])
+def test_load_shared_same_device(nsg, precision):
+    """nsg_load_shared: a second evaluator adopts the first one's network without reading the model
+    again (same device: one shared copy of the packed weights).  Same outputs bit for bit, different
+    batch capacities, and the source may be destroyed first."""
+    blob = nsg.weights.to_blob(nsg.weights.make_random(2, 128, seed=81, bn="random"))
+    bb = nsg.synth.random_batch(40, 86, seed=82)
+    a = nsg.Evaluator(0, 40, 86, precision=precision)
+    a.load_memory(blob)
+    ref = a.compute_blocking(bb)
+    b = nsg.Evaluator(0, 64, 86, precision=precision)
+    b.load_shared(a)
+    assert b.info()["loaded"] == 1 and b.info()["channels"] == 128 and b.info()["param_count"] == a.info()["param_count"]
+    for x, y in zip(b.compute_blocking(bb), ref):
+        np.testing.assert_array_equal(x, y)
+    a.close()  # the shared weights stay alive with their last user
+    for x, y in zip(b.compute_blocking(bb), ref):
+        np.testing.assert_array_equal(x, y)
+    c = nsg.Evaluator(0, 8, 86, precision="f16x3" if precision == "fp32" else "fp32")
+    with pytest.raises(nsg.NsgError, match="precision"):
+        c.load_shared(b)
+    d = nsg.Evaluator(0, 8, 86, precision=precision)
+    with pytest.raises(nsg.NsgError):
+        d.load_shared(c)  # nothing loaded in the source
