@@ -302,11 +302,11 @@ struct nsg_evaluator {
     DevBuf stamps;           // diagnostic builds: per-layer, per-workgroup cycle stamps
     DevBuf trunkLayers;      // persistent-trunk layer list (stem + 2 per block)
     int trunkLayerCount = 0;
-    // One persistent launch for all 3x3 layers (a workgroup owns its boards through every layer: no grid
-    // barrier).  -1 = automatic: the MX precisions when all tiles are resident in one round of workgroups
-    // (+1.6-2.4 % at B = 512 with kF16m6: the 40 launch boundaries; r1 measured +-0 % with kF16m8 and -6 % with
-    // kF16x3, which keep per-layer launches); NSG_TRUNK_KERNEL=0 / 1 forces it off / on.
-    int useTrunkKernel = -1;
+    // NSG_TRUNK_KERNEL=1: one persistent launch for all 3x3 layers (a workgroup owns its boards through every
+    // layer: no grid barrier).  Opt-in: with kF16m6 it measured +1.6-2.4 % at B = 512 on the benchmark's input (the
+    // initial position in every slot) but -1 % on distinct positions, +2.4-2.9 % at B = 256 / 384 and -3.4 % / -7 %
+    // at B = 192 / 160 (profiles/r02/g_ab_persistent_trunk_*.txt); r1: +-0 % kF16m8, -6 % kF16x3.
+    int useTrunkKernel = 0;
 
     void* trunkOut = nullptr; // which act[] holds the trunk output of the last forward
 
@@ -553,7 +553,7 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         else if (2 * tiles > cus && ev->chainDelayUs != 0 && ev->prec != nsg::kFp32) chains = std::min(ev->numChains, 2);
     }
     const bool stagger = oneRound && chains > 1;
-    const bool trunkWanted = ev->useTrunkKernel == 1 || (ev->useTrunkKernel < 0 && ev->prec == nsg::kF16m6 && oneRound);
+    const bool trunkWanted = ev->useTrunkKernel == 1;
     const bool trunkKernel = trunkWanted && !ev->W->outsideM8Window && nsg::canRunTrunk(ev->F, plan);
     if (trunkKernel) chains = 1;
     const int per = ((B + chains - 1) / chains + 1) / 2 * 2; // boards per chain, whole 2-board tiles
@@ -674,7 +674,7 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
         NSG_HIP(hipMemcpy(ev->trunkLayers.p, host.data(), host.size(), hipMemcpyHostToDevice));
         ev->trunkLayerCount = nl;
         const char* env = getenv("NSG_TRUNK_KERNEL");
-        ev->useTrunkKernel = env ? (env[0] == '1' ? 1 : 0) : -1;
+        ev->useTrunkKernel = (env && env[0] == '1') ? 1 : 0;
     }
     NSG_HIP(hipDeviceSynchronize());
     ev->calibKey = -1; // a new network: re-measure the layer time for the chain stagger
