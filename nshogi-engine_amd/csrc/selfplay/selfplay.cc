@@ -95,6 +95,10 @@ class Game {
         return false;
     }
 
+    // (leaf log) the position and StateConfig of the leaf waiting for its evaluation
+    std::string leafSfen() const { return S.toSfen(); }
+    const shogi::StateConfig& config() const { return Config; }
+
     // Frame::setEvaluation<false> (frame.cc:93-136) for the pending leaf.
     void setEvaluation(const float* Policy, float Win, float Draw) {
         const uint16_t N = Leaf->NumChildren;
@@ -551,6 +555,7 @@ int Engine::ownerOf(std::size_t GameIndex, std::size_t Games) const {
 Engine::Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& O, uint64_t EngineIndex, bool PinMemory,
                EvalCache* SharedCache)
     : Opt(O), Cache(SharedCache) {
+    EngineIndexForLogs = EngineIndex;
     if (Opt.Workers < 1) Opt.Workers = 1;
     if (Opt.Workers > Opt.GamesPerGroup) Opt.Workers = Opt.GamesPerGroup;
     for (int W = 0; W < Opt.Workers; ++W) Ctx.push_back(std::make_unique<WorkerCtx>());
@@ -696,6 +701,14 @@ void Engine::collect(Group& G) {
     }
     G.Count = N;
     if (N == 0) return;
+    if (Leaves) { // test hook: what sits in every slot of the packed batch, and the position it should encode
+        for (std::size_t K = 0; K < N; ++K) {
+            const Game& Gm = *G.Games[(std::size_t)G.Pending[K]];
+            Leaves->add(EngineIndexForLogs * 2 + (std::size_t)(&G == Groups[1].get()), St.Batches, K, Gm.leafSfen(), Gm.config().MaxPly,
+                        Gm.config().BlackDrawValue, Slots + K * shogi::NumFeaturePlanes,
+                        shogi::NumFeaturePlanes * sizeof(FeaturePlane));
+        }
+    }
     G.Ev->computeNonBlocking(N);
     G.InFlight = true;
     ++St.Batches;

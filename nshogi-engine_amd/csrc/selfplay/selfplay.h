@@ -115,6 +115,7 @@ struct Node {
 class Game; // one Frame
 class TeacherWriter; // teacher.h
 class GameLog;       // teacher.h: one line per finished game
+class LeafLog;       // teacher.h: test hook, one line per packed leaf
 
 // One engine = one search thread's worth of games + its two executors.
 class Engine {
@@ -135,6 +136,7 @@ class Engine {
     // Finished games are written to W (shared, not owned; nullptr = off).  Set before run().
     void setTeacherWriter(TeacherWriter* W) { Teacher = W; }
     void setGameLog(GameLog* L) { Log = L; }
+    void setLeafLog(LeafLog* L) { Leaves = L; }
 
     // Progress counters another thread may read while run() is going (the driver's rate timeline)
     uint64_t publishedFinished() const { return PubFinished.load(std::memory_order_relaxed); }
@@ -168,6 +170,8 @@ class Engine {
     Stats St; // engine-level counters: Batches, Evaluations
     TeacherWriter* Teacher = nullptr;
     GameLog* Log = nullptr;
+    LeafLog* Leaves = nullptr;
+    uint64_t EngineIndexForLogs = 0;
     std::vector<std::unique_ptr<WorkerCtx>> Ctx;
     std::vector<std::thread> Pool;
     const std::function<void(int)>* Task = nullptr;

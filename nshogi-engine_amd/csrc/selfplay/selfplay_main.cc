@@ -28,6 +28,9 @@
 //                               batch buffers there: evaluate::Evaluator, role of evaluator.cc:46-76)
 //                 [--teacher out.nsgt]   (training records of finished games, teacher.h)
 //                 [--game-log games.txt] (one line per finished game: id winner plies digest moves)
+//                 [--leaf-log leaves.txt] (tests: every leaf of every batch -- batch no., slot, SFEN, StateConfig, the
+//                                          1376 bytes the engine packed into that slot)
+//                 --executor hash: test executor whose outputs are a checksum of the position's own bitboards
 #include "selfplay.h"
 #include "teacher.h"
 
@@ -46,8 +49,38 @@
 
 using namespace nshogi::engine;
 
+namespace {
+// Test executor (--executor hash): every output is a pure function of the position's OWN feature
+// bitboards -- logits and rates derived from a checksum of its 1376 bytes -- so a leaf that received
+// another slot's outputs, or a batch packed out of order, changes the games; with it the
+// grouping-independence tests check the routing of evaluate -> scatter, not just the search.
+class HashInfer : public infer::Infer {
+ public:
+    void computeNonBlocking(const nshogi::ml::FeatureBitboard* Features, std::size_t BatchSize, float* DstPolicy,
+                            float* DstWinRate, float* DstDrawRate) override {
+        for (std::size_t B = 0; B < BatchSize; ++B) {
+            const uint64_t* W = reinterpret_cast<const uint64_t*>(Features + B * shogi::NumFeaturePlanes);
+            uint64_t H = 0x9e3779b97f4a7c15ULL;
+            for (int I = 0; I < 2 * shogi::NumFeaturePlanes; ++I) H = (H ^ W[I]) * 0xff51afd7ed558ccdULL + (H >> 29);
+            for (int I = 0; I < shogi::MoveIndexMax; ++I) {
+                uint64_t X = H + (uint64_t)I * 0xc4ceb9fe1a85ec53ULL;
+                X ^= X >> 31; X *= 0x9e3779b97f4a7c15ULL; X ^= X >> 29;
+                DstPolicy[B * shogi::MoveIndexMax + I] = (float)(X >> 40) * (4.0f / 16777216.0f) - 2.0f;
+            }
+            DstWinRate[B] = (float)((H >> 20) & 0xffff) / 65535.0f;
+            DstDrawRate[B] = (float)((H >> 40) & 0xffff) / 65535.0f * 0.5f;
+        }
+    }
+    void computeBlocking(const nshogi::ml::FeatureBitboard* F, std::size_t N, float* P, float* W, float* D) override {
+        computeNonBlocking(F, N, P, W, D);
+    }
+    void await() override {}
+    bool isComputing() override { return false; }
+};
+} // namespace
+
 int main(int Argc, char* Argv[]) {
-    std::string Executor = "hip", Weights, TeacherPath, GameLogPath;
+    std::string Executor = "hip", Weights, TeacherPath, GameLogPath, LeafLogPath;
     int Gpu = 0, NumGpus = 1, Threads = 2, Precision = NSG_PRECISION_F16X3;
     double Seconds = 30.0;
     uint64_t MaxGames = 0;
@@ -61,6 +94,7 @@ int main(int Argc, char* Argv[]) {
         else if (K == "--weights" || K == "--model") Weights = V;
         else if (K == "--teacher") TeacherPath = V;
         else if (K == "--game-log") GameLogPath = V;
+        else if (K == "--leaf-log") LeafLogPath = V;
         else if (K == "--dfpn-nodes") Opt.DfpnNodes = std::stoull(V);
         else if (K == "--gpu") Gpu = std::stoi(V);
         else if (K == "--num-gpus") NumGpus = std::stoi(V);
@@ -106,6 +140,8 @@ int main(int Argc, char* Argv[]) {
                 Execs.push_back(std::move(H));
             } else if (Executor == "zero") {
                 Execs.push_back(std::make_unique<infer::Zero>());
+            } else if (Executor == "hash") {
+                Execs.push_back(std::make_unique<HashInfer>());
             } else {
                 Execs.push_back(std::make_unique<infer::Random>((uint64_t)(2 * E + G))); // one engine state per executor
             }
@@ -120,6 +156,8 @@ int main(int Argc, char* Argv[]) {
     if (!TeacherPath.empty()) Teacher = std::make_unique<selfplay::TeacherWriter>(TeacherPath);
     std::unique_ptr<selfplay::GameLog> Log;
     if (!GameLogPath.empty()) Log = std::make_unique<selfplay::GameLog>(GameLogPath);
+    std::unique_ptr<selfplay::LeafLog> Leaves;
+    if (!LeafLogPath.empty()) Leaves = std::make_unique<selfplay::LeafLog>(LeafLogPath);
     // Every engine is built on the thread that runs it: with --numa the thread is first bound to its
     // GPU shard's NUMA node, so the engine's pinned batch buffers are first-touched there.
     std::vector<std::unique_ptr<selfplay::Engine>> Engines((std::size_t)NumEngines);
@@ -137,6 +175,7 @@ int main(int Argc, char* Argv[]) {
                 CacheMB ? Caches[ShareCache ? E / Threads : E].get() : nullptr);
             Engines[(std::size_t)E]->setTeacherWriter(Teacher.get());
             Engines[(std::size_t)E]->setGameLog(Log.get());
+            Engines[(std::size_t)E]->setLeafLog(Leaves.get());
             ++Built;
             while (!Go.load(std::memory_order_acquire)) std::this_thread::yield();
             Engines[(std::size_t)E]->run(&Stop, PerEngineGames);

@@ -80,6 +80,30 @@ void GameLog::add(uint64_t GameId, shogi::Color Winner, const std::vector<uint32
     std::fflush(Out);
 }
 
+LeafLog::LeafLog(const std::string& Path) {
+    Out = std::fopen(Path.c_str(), "w");
+    if (!Out) throw std::runtime_error("could not open the leaf log: " + Path);
+}
+
+LeafLog::~LeafLog() {
+    if (Out) std::fclose(Out);
+}
+
+void LeafLog::add(uint64_t Group, uint64_t Batch, std::size_t Slot, const std::string& Sfen, uint16_t MaxPly, float BlackDraw,
+                  const void* Planes, std::size_t Bytes) {
+    static const char* Digits = "0123456789abcdef";
+    std::string Hex;
+    Hex.reserve(Bytes * 2);
+    const unsigned char* P = static_cast<const unsigned char*>(Planes);
+    for (std::size_t I = 0; I < Bytes; ++I) {
+        Hex += Digits[P[I] >> 4];
+        Hex += Digits[P[I] & 15];
+    }
+    std::lock_guard<std::mutex> Lock(Mutex);
+    std::fprintf(Out, "%llu\t%llu\t%zu\t%s\t%u\t%.9g\t%s\n", (unsigned long long)Group, (unsigned long long)Batch, Slot,
+                 Sfen.c_str(), (unsigned)MaxPly, (double)BlackDraw, Hex.c_str());
+}
+
 } // namespace selfplay
 } // namespace engine
 } // namespace nshogi

@@ -81,6 +81,24 @@ class GameLog {
     std::mutex Mutex;
 };
 
+// Test hook of the host batch packing (selfplay::EvaluationWorker::doTask's role): one text
+// line per leaf of every batch -- engine group, batch number, slot, the leaf's SFEN, its StateConfig (MaxPly,
+// BlackDrawValue) and the 1376 bytes found in that slot of the pinned batch buffer AFTER packing (hex) -- so a
+// test can rebuild what the slot should hold from the SFEN alone.
+class LeafLog {
+ public:
+    explicit LeafLog(const std::string& Path);
+    ~LeafLog();
+    LeafLog(const LeafLog&) = delete;
+    LeafLog& operator=(const LeafLog&) = delete;
+    void add(uint64_t Group, uint64_t Batch, std::size_t Slot, const std::string& Sfen, uint16_t MaxPly, float BlackDraw,
+             const void* Planes, std::size_t Bytes);
+
+ private:
+    std::FILE* Out = nullptr;
+    std::mutex Mutex;
+};
+
 } // namespace selfplay
 } // namespace engine
 } // namespace nshogi

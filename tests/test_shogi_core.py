@@ -258,3 +258,57 @@ def test_selfplay_hip_reproducible(nsg, tmp_path):
     b = json.loads(run("selfplay", *base))
     assert a["games_finished"] >= 4 and a["digest"] == b["digest"] and a["moves"] == b["moves"]
     assert a["evals_per_sec"] > 0 and 0 <= a["cache_hit_ratio"] < 1
+
+
+def test_selfplay_packed_batches_against_the_sfen_restatement(tmp_path):
+    """Host batch packing of the self-play path (selfplay::EvaluationWorker::doTask, SURVEY.md 8a a10):
+    for EVERY leaf of every batch, the 1376 bytes the engine packed into that slot of the pinned batch
+    buffer expand to the planes tests/shogi_ref.py writes from the leaf's SFEN and StateConfig alone
+    (MaxPly and the draw values differ from game to game, worker.cc:132-150); slots are 0..N-1 without
+    gaps, also with several host workers packing their own slot ranges."""
+    import shogi_ref
+    import oracle_lib
+    orc = oracle_lib.load()
+    for workers in (1, 3):
+        path = tmp_path / f"leaves{workers}.txt"
+        run("selfplay", "--executor", "hash", "--threads", "1", "--workers", workers, "--games-per-group", "7",
+            "--playouts", "40", "--max-games", "3", "--seed", "6", "--dfpn-nodes", "2000", "--leaf-log", path)
+        rows = [ln.rstrip("\n").split("\t") for ln in open(path)]
+        assert len(rows) > 3000
+        batches = {}
+        for grp, batch, slot, sfen, max_ply, black_draw, hexes in rows:
+            batches.setdefault((grp, batch), []).append(int(slot))
+        assert all(sorted(v) == list(range(len(v))) for v in batches.values())  # contiguous slots per batch
+        assert max(len(v) for v in batches.values()) == 7
+        pick = np.random.default_rng(workers).choice(len(rows), size=600, replace=False)
+        sample = [rows[i] for i in sorted(pick)]
+        bb = np.stack([np.frombuffer(bytes.fromhex(r[6]), dtype="<u8").reshape(86, 2) for r in sample])
+        got = orc.extract_bits(bb, True)
+        configs = set()
+        for r, planes in zip(sample, got):
+            want = shogi_ref.expected_planes(r[3], int(r[4]), float(r[5]))
+            np.testing.assert_array_equal(planes, want, err_msg=r[3])
+            configs.add((r[4], r[5]))
+        assert len(configs) > 3  # per-game StateConfigs really differ
+
+
+def test_selfplay_routing_with_a_position_dependent_executor(tmp_path):
+    """--executor hash returns, per position, outputs derived from a checksum of that position's own
+    feature bitboards.  A leaf that received another slot's outputs would play a different game: the
+    per-game logs must be the same for every way of spreading the game slots (the routing half of a10
+    and of feedResult / Frame::setEvaluation, a11)."""
+    base = ["--executor", "hash", "--playouts", "48", "--seed", "12", "--dfpn-nodes", "2000", "--max-games", "8"]
+    logs = []
+    for i, shape in enumerate((["--threads", "1", "--games-per-group", "6"],
+                               ["--threads", "3", "--games-per-group", "2"],
+                               ["--num-gpus", "2", "--threads", "1", "--workers", "2", "--games-per-group", "3"],
+                               ["--threads", "1", "--workers", "3", "--solver-threads", "2", "--games-per-group", "6"])):
+        path = tmp_path / f"r{i}.log"
+        out = json.loads(run("selfplay", *base, *shape, "--game-log", path, "--evaluation-cache-memory-size", "0" if i == 1 else "64"))
+        assert out["concurrent_games"] == 12
+        logs.append(_game_log(path))
+    common = set(logs[0]) & set(logs[1]) & set(logs[2]) & set(logs[3])
+    assert len(common) >= 5
+    for gid in common:
+        assert logs[0][gid] == logs[1][gid] == logs[2][gid] == logs[3][gid], gid
+    assert len({logs[0][g] for g in common}) == len(common)  # and the games differ from one another
