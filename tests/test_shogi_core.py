@@ -226,14 +226,15 @@ def test_selfplay_windowed_rate_and_cache_options():
 def test_selfplay_hip_games_do_not_depend_on_grouping(nsg, tmp_path, monkeypatch):
     """The same on the HIP evaluator, in the arithmetic that does not depend on the batch size: the
     f32 path with one fixed tile plan (NSG_CONV_NB=1, NSG_CONV_NFRAG=4 -- by default the plan, and
-    with it the f32 summation order, follows the batch size).  Cache hits return what a fresh
-    evaluation would, so the evaluation cache does not disturb this either."""
+    with it the f32 summation order, follows the batch size).  The evaluation cache is off: like the
+    reference's it is keyed by the position alone while the planes also carry the ply and the game's
+    StateConfig, so a hit may hand a game another game's evaluation of the same board."""
     monkeypatch.setenv("NSG_CONV_NB", "1")
     monkeypatch.setenv("NSG_CONV_NFRAG", "4")
     path = tmp_path / "net.nsgw"
     nsg.weights.save(str(path), nsg.weights.make_random(2, 64, seed=3, bn="random"))
     base = ["--executor", "hip", "--weights", str(path), "--precision", "0", "--playouts", "24", "--seed", "9",
-            "--max-games", "8", "--dfpn-nodes", "2000"]
+            "--max-games", "8", "--dfpn-nodes", "2000", "--evaluation-cache-memory-size", "0"]
     logs = []
     for i, shape in enumerate((["--threads", "1", "--games-per-group", "6"], ["--threads", "2", "--games-per-group", "3"])):
         lp = tmp_path / f"h{i}.log"
@@ -304,7 +305,9 @@ def test_selfplay_routing_with_a_position_dependent_executor(tmp_path):
                                ["--num-gpus", "2", "--threads", "1", "--workers", "2", "--games-per-group", "3"],
                                ["--threads", "1", "--workers", "3", "--solver-threads", "2", "--games-per-group", "6"])):
         path = tmp_path / f"r{i}.log"
-        out = json.loads(run("selfplay", *base, *shape, "--game-log", path, "--evaluation-cache-memory-size", "0" if i == 1 else "64"))
+        # (no evaluation cache: like the reference's, it is keyed by the position alone, while the planes also
+        # carry the ply and the game's StateConfig -- a hit may return another game's evaluation of the board)
+        out = json.loads(run("selfplay", *base, *shape, "--game-log", path, "--evaluation-cache-memory-size", "0"))
         assert out["concurrent_games"] == 12
         logs.append(_game_log(path))
     common = set(logs[0]) & set(logs[1]) & set(logs[2]) & set(logs[3])
