@@ -225,6 +225,22 @@ struct Args {
     unsigned long long* stamps; // diagnostic builds only (NSG_DIAG_STAMPS): 8 u64 per workgroup
 };
 
+// What tileKernel takes behind its preloaded scalar arguments.
+struct ArgsTail {
+    float* policy;
+    unsigned char* vfeat;
+    int totalRows;
+    int valueChannels;
+    int vfeatStride;
+    int outF16x3;
+    int kSplits;
+    size_t partStride;
+    unsigned long long* stamps;
+};
+inline ArgsTail tailOf(const Args& a) {
+    return ArgsTail{a.policy, a.vfeat, a.totalRows, a.valueChannels, a.vfeatStride, a.outF16x3, a.kSplits, a.partStride, a.stamps};
+}
+
 #ifdef NSG_DIAG_STAMPS
 #define NSG_STAMP(IDX)                                                                       \
     do {                                                                                     \
@@ -1275,8 +1291,16 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 }
 
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES, int MS = 1, int KS = 1>
-__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG, PREC>())) void tileKernel(const Args A) {
+__global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG, PREC>())) void tileKernel(
+    // The fourteen dwords every conv prologue needs come first as plain arguments: the build
+    // preloads them into SGPRs at wave launch (-amdgpu-kernarg-preload-count, a by-value struct
+    // is not eligible), so the tile requests do not wait for a cold scalar load of the argument
+    // block first.  The rest travels as a struct and is read where it is used.
+    const unsigned char* x, const u32x4* w, const unsigned char* res, unsigned char* y, const float* bias,
+    int kdim, int cout, int relu, float accScale, const ArgsTail T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Args A{x, w, bias, res, y, T.policy, T.vfeat, kdim, cout, T.totalRows, relu, T.valueChannels,
+                 T.vfeatStride, accScale, T.outF16x3, T.kSplits, T.partStride, T.stamps};
     tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS>(A, smem, true);
 }
 
@@ -1328,7 +1352,8 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
             if (err != hipSuccess) return err;
             attrDevMask.fetch_or(1 << dev);
         }
-        hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a);
+        hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a.x, a.w, a.res, a.y, a.bias,
+                           a.kdim, a.cout, a.relu, a.accScale, tailOf(a));
     } else {
         auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false, MS, KS>;
         static std::atomic<int> attrDevMask{0};
@@ -1339,7 +1364,8 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
             if (err != hipSuccess) return err;
             attrDevMask.fetch_or(1 << dev);
         }
-        hipLaunchKernelGGL(k, dim3(gridX, gy, MODE == kDense ? a.kSplits : 1), dim3(G::kThreads), G::kLdsAlloc, stream, a);
+        hipLaunchKernelGGL(k, dim3(gridX, gy, MODE == kDense ? a.kSplits : 1), dim3(G::kThreads), G::kLdsAlloc, stream,
+                           a.x, a.w, a.res, a.y, a.bias, a.kdim, a.cout, a.relu, a.accScale, tailOf(a));
     }
     return hipGetLastError();
 }
