@@ -53,6 +53,7 @@
 #include "kernels.h"
 
 #include <atomic>
+#include <type_traits>
 
 namespace nsg {
 namespace tile {
@@ -115,21 +116,26 @@ __device__ __forceinline__ void zeroHalo(unsigned char* smem, int tid) {
     constexpr int kPlanes = G::kLds / G::kPlane;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int kWavesN = G::kThreads / 64;
+    // Straight-line code: a lane or plane with nothing left to clear writes entry 0 (a leading halo
+    // entry, zero anyway) of the last plane again.  The predicated form compiled to one out-of-line
+    // block per store at the far end of the kernel: an instruction-cache miss each, in the prologue
+    // of every layer.
 #pragma unroll
     for (int h0 = 0; h0 < kHalo; h0 += 64) {
         const int h = h0 + lane;
         int e = h; // h < 24: the leading entries
-        if (h >= 24) {
+        if (h0 + 63 >= 24) {
             const int q = h - 24, b = q / 29, r = q - b * 29;
             const int within = r < 10 ? r : (r < 19 ? (r - 9) * 10 + 9 : 81 + r); // y = -1 | x = 9 of y = 0..8 | y = 9
-            e = b < kBoardsN ? 24 + b * 110 + within : G::kEntries + (q - 29 * kBoardsN);
+            const int eb = b < kBoardsN ? 24 + b * 110 + within : G::kEntries + (q - 29 * kBoardsN);
+            e = h < 24 ? h : eb;
         }
-        if (h < kHalo) {
-            unsigned char* p = smem + e * 16 + wave * G::kPlane;
+        e = h < kHalo ? e : 0;
 #pragma unroll
-            for (int pl = 0; pl < (kPlanes + kWavesN - 1) / kWavesN; ++pl)
-                if (pl * kWavesN + wave < kPlanes)
-                    *reinterpret_cast<u32x4*>(p + (size_t)pl * kWavesN * G::kPlane) = u32x4{0u, 0u, 0u, 0u};
+        for (int pl = 0; pl < (kPlanes + kWavesN - 1) / kWavesN; ++pl) {
+            int plane = pl * kWavesN + wave;
+            plane = plane < kPlanes ? plane : kPlanes - 1;
+            *reinterpret_cast<u32x4*>(smem + e * 16 + (size_t)plane * G::kPlane) = u32x4{0u, 0u, 0u, 0u};
         }
     }
 }
@@ -957,10 +963,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         };
         // kF16m8, last trunk layer: the output is written in the kF16x3 layout (hi, f16 lo)
         const bool outX3 = kM8 && A.outF16x3;
-        auto pieceOffOut = [&](int k) -> int {
-            if (kM8 && outX3) return (g >> 1) * 128 + (g & 1) * 32 + (k & 1) * 16 + (k >> 1) * 64;
-            return pieceOff(k);
-        };
+        auto pieceOffX3 = [&](int k) -> int { return (g >> 1) * 128 + (g & 1) * 32 + (k & 1) * 16 + (k >> 1) * 64; };
         const int lrow = lane / kPPR;   // lane-linear view: row within an instruction
         const int lpc = lane % kPPR;    //                   piece within the row
         // global addresses = wave-uniform row base (scalar arithmetic) + one per-lane 32-bit offset
@@ -1126,7 +1129,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                             op[2 + k][i] = l2;
                         }
                 } else if constexpr (kM8) {
-                    if (outX3) {
+                    if (__builtin_expect(outX3, false)) {
 #pragma unroll
                         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -1222,7 +1225,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                         for (int i = 0; i < 4; ++i) op[k][i] = packPair<PREC>(v[k * 8 + 2 * i], v[k * 8 + 2 * i + 1]);
                 }
 #pragma unroll
-                for (int k = 0; k < kNP; ++k) *reinterpret_cast<u32x4*>(lrowp + pieceOffOut(k)) = op[k];
+                for (int k = 0; k < kNP; ++k) *reinterpret_cast<u32x4*>(lrowp + (__builtin_expect(outX3, false) ? pieceOffX3(k) : pieceOff(k))) = op[k];
             }
             if (i >= 1) { // ---- S(i-1), stores: kRPI rows x kRowB contiguous bytes per instruction
                 const int f = i - 1;
