@@ -368,7 +368,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
             for (int k = 0; k < G::kItems; ++k) {
                 stAll[c][k] = u32x4{0u, 0u, 0u, 0u};
-                if (c < nkc) stAll[c][k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)c * 128);
+                if (__builtin_expect(c < nkc, 1)) stAll[c][k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)c * 128);
             }
         __builtin_amdgcn_sched_barrier(0);
         NSG_STAMP(4); // (diagnostic builds) every tile load issued
@@ -381,7 +381,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // masked lanes store to their own trash slot behind both buffers (one shared slot made
         // every masked store a 64-way same-address conflict that stalled the whole LDS): the store
         // stays unconditional, so st[] stays in registers
-        dstOff[k] = itemOk[k] ? c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16 : G::kLds + lane * 16;
+        // (bit select, not ?: -- the compiler turned the conditional into a far out-of-line block per item)
+        const int okOff = c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16, okMask = -(int)itemOk[k];
+        dstOff[k] = (okOff & okMask) | ((G::kLds + lane * 16) & ~okMask);
     }
 
     // per-lane LDS read bases of the row fragments
@@ -487,7 +489,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             for (int c = 0; c < kChunks; ++c)
 #pragma unroll
                 for (int k = 0; k < G::kItems; ++k)
-                    if (c < nkc) *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? c * G::kBuf : 0) + dstOff[k]) = stAll[c][k];
+                    if (__builtin_expect(c < nkc, 1)) *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? c * G::kBuf : 0) + dstOff[k]) = stAll[c][k];
             __syncthreads();
         }
         NSG_STAMP(1);
@@ -987,7 +989,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 for (int it = 0; it < kIPF; ++it) {
                     const int m = (fBaseE + f) * 16 + it * kRPI + lrow;
                     rpre[f][it] = u32x4{0u, 0u, 0u, 0u};
-                    if (m < G::kRows)
+                    if (__builtin_expect(m < G::kRows, 1))
                         rpre[f][it] = *reinterpret_cast<const u32x4*>(resBase + (size_t)(NSG_RES_FRAG(f) * 16 + it * kRPI) * rowBytes + laneOff);
                 }
         }
@@ -1021,7 +1023,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     if (f < kPreFrags) {
                         t = rpre[f < kPreFrags ? f : 0][it];
                     } else {
-                        if (m < G::kRows)
+                        if (__builtin_expect(m < G::kRows, 1))
                             t = *reinterpret_cast<const u32x4*>(resBase + (size_t)(NSG_RES_FRAG(f) * 16 + it * kRPI) * rowBytes + laneOff);
                     }
                     *reinterpret_cast<u32x4*>(ebuf + (f % kRegions) * kFragBytes + r * kRowS + lpc * 16) = t;
@@ -1232,7 +1234,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
                     const int m = (fBaseE + f) * 16 + it * kRPI + lrow;
-                    if (m < G::kRows)
+                    if (__builtin_expect(m < G::kRows, 1))
                         *reinterpret_cast<u32x4*>(yBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff) = tt[it];
                 }
             }
