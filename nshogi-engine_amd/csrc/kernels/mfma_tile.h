@@ -238,25 +238,33 @@ struct ArgsTail {
     int totalRows;
     int valueChannels;
     int vfeatStride;
-    int outF16x3;
     int kSplits;
     size_t partStride;
     unsigned long long* stamps;
 };
 inline ArgsTail tailOf(const Args& a) {
-    return ArgsTail{a.policy, a.vfeat, a.totalRows, a.valueChannels, a.vfeatStride, a.outF16x3, a.kSplits, a.partStride, a.stamps};
+    return ArgsTail{a.policy, a.vfeat, a.totalRows, a.valueChannels, a.vfeatStride, a.kSplits, a.partStride, a.stamps};
 }
 
 #ifdef NSG_DIAG_STAMPS
+// Stamp 0 (and its wall-clock twin) is held in scalar registers and written with stamp 1: A.stamps is
+// not among the preloaded arguments, and the first stamp must not wait for the argument block's tail.
+#define NSG_STAMP_DECL unsigned long long nsgStamp0 = 0, nsgReal0 = 0;
 #define NSG_STAMP(IDX)                                                                       \
     do {                                                                                     \
-        if (A.stamps && threadIdx.x == 0) {                                                  \
-            A.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (IDX)] = __builtin_amdgcn_s_memtime(); \
-            if ((IDX) == 0) A.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
-            if ((IDX) == 3) A.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime(); \
+        if ((IDX) == 0) {                                                                    \
+            nsgStamp0 = __builtin_amdgcn_s_memtime();                                        \
+            nsgReal0 = __builtin_amdgcn_s_memrealtime();                                     \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        } else if (A.stamps && threadIdx.x == 0) {                                           \
+            unsigned long long* o_ = A.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8; \
+            o_[(IDX)] = __builtin_amdgcn_s_memtime();                                        \
+            if ((IDX) == 1) { o_[0] = nsgStamp0; o_[7] = nsgReal0; }                         \
+            if ((IDX) == 3) o_[6] = __builtin_amdgcn_s_memrealtime();                        \
         }                                                                                    \
     } while (0)
 #else
+#define NSG_STAMP_DECL
 #define NSG_STAMP(IDX) do { } while (0)
 #endif
 
@@ -306,6 +314,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     static_assert(KS == 1 || (isMx(PREC) && MODE == kConv && SIZE == 1 && MS == 1 && NWAVES % KS == 0),
                   "K split: kF16m8 one-board conv tiles");
     const bool hasRes = (RES == 1) || (RES == 2 && A.res != nullptr);
+    NSG_STAMP_DECL
     NSG_STAMP(0);
     constexpr bool kM8 = isMx(PREC);          // f16 main term + MX correction terms (the kF16m8 main loop)
     constexpr bool kM6 = (PREC == kF16m6);    // ... with e2m3 operands and per-block E8M0 scales
@@ -472,8 +481,10 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         NSG_STAGE_LOAD(0)
 #pragma unroll
         for (int k = 0; k < G::kItems; ++k) st1[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + 128);
+        NSG_STAMP(4);
         if (zeroLds) zeroHalo<G>(smem, tid);
         __syncthreads(); // zero fill done before staging writes
+        NSG_STAMP(5);
         NSG_STAGE_WRITE(0)
 #pragma unroll
         for (int k = 0; k < G::kItems; ++k)
@@ -1302,10 +1313,10 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, N
     // is not eligible), so the tile requests do not wait for a cold scalar load of the argument
     // block first.  The rest travels as a struct and is read where it is used.
     const unsigned char* x, const u32x4* w, const unsigned char* res, unsigned char* y, const float* bias,
-    int kdim, int cout, int relu, float accScale, const ArgsTail T) {
+    int kdim, int cout, int flags /* bit 0: relu, bit 1: outF16x3 */, float accScale, const ArgsTail T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Args A{x, w, bias, res, y, T.policy, T.vfeat, kdim, cout, T.totalRows, relu, T.valueChannels,
-                 T.vfeatStride, accScale, T.outF16x3, T.kSplits, T.partStride, T.stamps};
+    const Args A{x, w, bias, res, y, T.policy, T.vfeat, kdim, cout, T.totalRows, flags & 1, T.valueChannels,
+                 T.vfeatStride, accScale, (flags >> 1) & 1, T.kSplits, T.partStride, T.stamps};
     tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS>(A, smem, true);
 }
 
@@ -1358,7 +1369,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
             attrDevMask.fetch_or(1 << dev);
         }
         hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a.x, a.w, a.res, a.y, a.bias,
-                           a.kdim, a.cout, a.relu, a.accScale, tailOf(a));
+                           a.kdim, a.cout, (a.relu ? 1 : 0) | (a.outF16x3 ? 2 : 0), a.accScale, tailOf(a));
     } else {
         auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false, MS, KS>;
         static std::atomic<int> attrDevMask{0};
@@ -1370,7 +1381,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
             attrDevMask.fetch_or(1 << dev);
         }
         hipLaunchKernelGGL(k, dim3(gridX, gy, MODE == kDense ? a.kSplits : 1), dim3(G::kThreads), G::kLdsAlloc, stream,
-                           a.x, a.w, a.res, a.y, a.bias, a.kdim, a.cout, a.relu, a.accScale, tailOf(a));
+                           a.x, a.w, a.res, a.y, a.bias, a.kdim, a.cout, (a.relu ? 1 : 0) | (a.outF16x3 ? 2 : 0), a.accScale, tailOf(a));
     }
     return hipGetLastError();
 }
