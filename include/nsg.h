@@ -194,6 +194,12 @@ int nsg_download_outputs(nsg_evaluator* ev, size_t batch_size,
                          float* dst_draw_rate);
 /* Debug read-back of the trunk output as fp32 [batch][F][81] (NCHW). */
 int nsg_download_trunk(nsg_evaluator* ev, size_t batch_size, float* dst);
+/* Debug read-back of the trunk INPUT exactly as the last forward's plane
+ * expansion wrote it: raw bytes, [batch][81][padded channels] in the trunk
+ * precision's element layout; *row_bytes receives the
+ * bytes per (board, square).  capacity is checked. */
+int nsg_download_planes_raw(nsg_evaluator* ev, size_t batch_size, void* dst,
+                            size_t capacity, size_t* row_bytes);
 
 /* HIP-event timing of the dominant kernel (the F->F 3x3 residual
  * convolution) on the evaluator's own stream.  While enabled, every forward

@@ -92,6 +92,7 @@ def load_library():
     lib.nsg_forward_resident.argtypes = [vp, sz]
     lib.nsg_download_outputs.argtypes = [vp, sz, vp, vp, vp]
     lib.nsg_download_trunk.argtypes = [vp, sz, vp]
+    lib.nsg_download_planes_raw.argtypes = [vp, sz, vp, sz, ctypes.POINTER(ctypes.c_size_t)]
     lib.nsg_profile_enable.argtypes = [vp, i]
     lib.nsg_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_uint64),
@@ -266,6 +267,15 @@ class Evaluator:
         out = np.empty((int(batch_size), info["channels"], NUM_SQUARES), dtype=np.float32)
         _check(self._lib.nsg_download_trunk(self._h, int(batch_size), _ptr(out)))
         return out
+
+    def download_planes_raw(self, batch_size):
+        """The trunk input of the last forward as raw bytes [batch][81][row_bytes] (debug read-back)."""
+        info = self.info()
+        cap = int(batch_size) * NUM_SQUARES * 4 * 4 * ((info["num_channels"] + 127) // 128 * 128)
+        buf = np.empty(cap, dtype=np.uint8)
+        rb = ctypes.c_size_t()
+        _check(self._lib.nsg_download_planes_raw(self._h, int(batch_size), _ptr(buf), cap, ctypes.byref(rb)))
+        return buf[: int(batch_size) * NUM_SQUARES * rb.value].reshape(int(batch_size), NUM_SQUARES, rb.value)
 
     def profile_enable(self, enable=True):
         _check(self._lib.nsg_profile_enable(self._h, 1 if enable else 0))

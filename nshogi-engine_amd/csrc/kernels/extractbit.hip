@@ -201,78 +201,66 @@ __global__ __launch_bounds__(kThreads) void extractAct(
 }
 
 // ---- kF16m6 trunk input: per (square, 32-channel chunk) one 128-byte row
-// [32 x f16 hi][e2m3(hi) block][e2m3(lo) block], each block 24 B of codes +
-// its E8M0 exponent (kernels.h).  One thread per (square, chunk); values are plane bits and four
-// scalar planes, so a software encoder is plenty here (the trunk's epilogue uses the packed
-// conversion instructions).
-__device__ __forceinline__ unsigned encodeE2m3(float q) { // q already divided by the block scale; RNE, saturating
-    const unsigned sign = (__float_as_uint(q) >> 31) << 5;
-    const float a = fabsf(q);
-    if (!(a < 7.5f)) return sign | 0x1fu;
-    const int ex = a >= 4.f ? 2 : (a >= 2.f ? 1 : 0);
-    const float step = ex == 2 ? 0.5f : (ex == 1 ? 0.25f : 0.125f);
-    const float r = rintf(a / step) * step;
-    if (r >= 7.5f) return sign | 0x1fu;
-    if (r < 1.f) return sign | (unsigned)(r * 8.f);
-    const int e2 = r >= 4.f ? 2 : (r >= 2.f ? 1 : 0);
-    const float st2 = e2 == 2 ? 0.5f : (e2 == 1 ? 0.25f : 0.125f);
-    return sign | (unsigned)(((e2 + 1) << 3) | (((int)(r / st2) - 8) & 7));
-}
-// 32 values (slot order) -> 24 bytes of codes + exponent byte at [24]
-__device__ __forceinline__ void packE2m3BlockDev(const float* v, unsigned char* out) {
-    float m = 0.f;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) m = fmaxf(m, fabsf(v[j]));
-    const unsigned ef = __float_as_uint(m) >> 23;          // biased exponent of the maximum (m >= 0)
-    const unsigned e8 = m > 0.f ? (ef > 3u ? ef - 2u : 1u) : 0u;
-    const float inv = __uint_as_float((254u - e8) << 23);  // 2^(127 - e8)
-    uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const unsigned code = e8 ? encodeE2m3(v[j] * inv) : 0u;
-        const int bit = 6 * j;
-        w[bit / 32] |= code << (bit % 32);
-        if (bit % 32 > 26) w[bit / 32 + 1] |= code >> (32 - bit % 32);
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) reinterpret_cast<uint32_t*>(out)[i] = w[i];
-    reinterpret_cast<uint32_t*>(out)[6] = e8;
-    reinterpret_cast<uint32_t*>(out)[7] = 0u;
-}
+// [32 x f16 hi][e2m3(hi) block][e2m3(lo) block], each block 24 B of codes + its E8M0 exponent
+// in the dword behind them (kernels.h).  One thread per (square, chunk): it holds the chunk's 32
+// values, so the block maxima need no cross-lane step and each block is ONE
+// v_cvt_scalef32_pk32_fp6_f16 -- the same rule as the trunk's epilogue (mfma_tile.h: exponent =
+// f16 exponent of the block maximum + 110, i.e. the float exponent minus 2; a zero block gets
+// 2^-17 and all-zero codes).
+constexpr int kThreadsM6 = 384; // 81 squares x 4 chunks = 324 items of the stem's 128 channels in one round
 
-__global__ __launch_bounds__(kThreads) void extractActM6(
+__global__ __launch_bounds__(kThreadsM6) void extractActM6(
     unsigned char* __restrict__ dst, const uint4* __restrict__ src, int channels, int cpad) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+    typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) uint4 sBoard[];
     const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < channels; c += kThreads) sBoard[c] = src[(size_t)b * channels + c];
+    for (int c = threadIdx.x; c < channels; c += kThreadsM6) sBoard[c] = src[(size_t)b * channels + c];
     __syncthreads();
     const int chunks = cpad / 32;
-    for (int it = threadIdx.x; it < 81 * chunks; it += kThreads) {
+    for (int it = threadIdx.x; it < 81 * chunks; it += kThreadsM6) {
         const int sq = it / chunks, kc = it - sq * chunks;
-        float hi[32], lo[32];
-        uint32_t hbits[16];
+        uint32_t hp[16], lp[16];
+        u16x2 mh = {0, 0}, ml = {0, 0}; // running maxima of |hi|, |lo| as f16 bit patterns (order-preserving)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int c = kc * 32 + i;
-            float v = 0.f;
-            if (c < channels) {
-                const uint4 bb = sBoard[c];
-                const uint64_t l64 = ((uint64_t)bb.y << 32) | bb.x;
-                const uint64_t h64 = ((uint64_t)bb.w << 32) | bb.z;
-                v = fminf(fmaxf(__uint_as_float(selectBit(l64, h64, sq)), -65000.f), 65000.f);
+        for (int d = 0; d < 16; ++d) {
+            f32x2 v = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = kc * 32 + 2 * d + q;
+                if (c < channels) {
+                    const uint4 bb = sBoard[c];
+                    const uint64_t l64 = ((uint64_t)bb.y << 32) | bb.x;
+                    const uint64_t h64 = ((uint64_t)bb.w << 32) | bb.z;
+                    v[q] = __builtin_amdgcn_fmed3f(__uint_as_float(selectBit(l64, h64, sq)), -65000.f, 65000.f);
+                }
             }
-            const _Float16 h = (_Float16)v;
-            hi[i] = (float)h;
-            lo[i] = v - (float)h;
-            const uint32_t hb = __builtin_bit_cast(uint16_t, h);
-            if (i & 1) hbits[i >> 1] |= hb << 16; else hbits[i >> 1] = hb;
+            const f16x2 h = __builtin_convertvector(v, f16x2);
+            const f32x2 lx = v - __builtin_convertvector(h, f32x2);
+            hp[d] = __builtin_bit_cast(uint32_t, h);
+            lp[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lx, f16x2));
+            mh = __builtin_elementwise_max(mh, __builtin_bit_cast(u16x2, hp[d] & 0x7fff7fffu));
+            ml = __builtin_elementwise_max(ml, __builtin_bit_cast(u16x2, lp[d] & 0x7fff7fffu));
         }
-        unsigned char* row = dst + ((size_t)b * 81 + sq) * cpad * 4 + (size_t)kc * 128;
+        const uint32_t eh = ((uint32_t)(mh[0] > mh[1] ? mh[0] : mh[1]) >> 10) + 110u;
+        const uint32_t el = ((uint32_t)(ml[0] > ml[1] ? ml[0] : ml[1]) >> 10) + 110u;
+        const u32x16 hsrc = {hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7],
+                             hp[8], hp[9], hp[10], hp[11], hp[12], hp[13], hp[14], hp[15]};
+        const u32x16 lsrc = {lp[0], lp[1], lp[2], lp[3], lp[4], lp[5], lp[6], lp[7],
+                             lp[8], lp[9], lp[10], lp[11], lp[12], lp[13], lp[14], lp[15]};
+        u32x6 hb, lb; // (early clobber: the builtin may place the result inside its source, mfma_tile.h)
+        asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(hb) : "v"(hsrc), "v"(__uint_as_float(eh << 23)));
+        asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(lb) : "v"(lsrc), "v"(__uint_as_float(el << 23)));
+        uint4* row = reinterpret_cast<uint4*>(dst + ((size_t)b * 81 + sq) * cpad * 4 + (size_t)kc * 128);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            reinterpret_cast<uint4*>(row)[i] = make_uint4(hbits[4 * i], hbits[4 * i + 1], hbits[4 * i + 2], hbits[4 * i + 3]);
-        packE2m3BlockDev(hi, row + 64);
-        packE2m3BlockDev(lo, row + 96);
+        for (int i = 0; i < 4; ++i) row[i] = make_uint4(hp[4 * i], hp[4 * i + 1], hp[4 * i + 2], hp[4 * i + 3]);
+        row[4] = make_uint4(hb.s0, hb.s1, hb.s2, hb.s3);
+        row[5] = make_uint4(hb.s4, hb.s5, eh, 0u);
+        row[6] = make_uint4(lb.s0, lb.s1, lb.s2, lb.s3);
+        row[7] = make_uint4(lb.s4, lb.s5, el, 0u);
     }
 }
 
@@ -341,7 +329,7 @@ hipError_t launchExtractBitsAct(void* dst, const uint64_t* src, int batch,
                            stream, dst, (const uint4*)src, channels, cpad);
     } else if (prec == kF16m6) {
         if (cpad % 32 != 0) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(extractActM6, dim3(batch), dim3(kThreads), smem,
+        hipLaunchKernelGGL(extractActM6, dim3(batch), dim3(kThreadsM6), smem,
                            stream, (unsigned char*)dst, (const uint4*)src, channels, cpad);
     } else {
         hipLaunchKernelGGL(extractAct<kBf16>, dim3(batch), dim3(kThreads), smem,

@@ -1180,6 +1180,21 @@ int nsg_download_trunk(nsg_evaluator* ev, size_t batch_size, float* dst) {
     return NSG_OK;
 }
 
+int nsg_download_planes_raw(nsg_evaluator* ev, size_t batch_size, void* dst, size_t capacity, size_t* row_bytes) {
+    int rc = checkCompute(ev, batch_size);
+    if (rc) return rc;
+    if (!ev->trunkOut) return fail(NSG_E_INVALID, "no forward has run yet");
+    if (!dst || !row_bytes) return fail(NSG_E_INVALID, "null argument");
+    const size_t es = nsg::elemSize(ev->lastTrunkPrec);
+    const size_t rb = (size_t)ev->cpad * es;
+    const size_t bytes = batch_size * 81 * rb;
+    if (capacity < bytes) return fail(NSG_E_INVALID, "destination holds %zu bytes, %zu needed", capacity, bytes);
+    NSG_HIP(hipMemcpyAsync(dst, ev->planes.p, bytes, hipMemcpyDeviceToHost, ev->stream));
+    NSG_HIP(hipStreamSynchronize(ev->stream));
+    *row_bytes = rb;
+    return NSG_OK;
+}
+
 int nsg_profile_enable(nsg_evaluator* ev, int enable) {
     if (!ev) return fail(NSG_E_INVALID, "null evaluator");
     int rc = bind(ev);

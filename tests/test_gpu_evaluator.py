@@ -278,6 +278,63 @@ def test_f16m8_extreme_magnitudes_stay_finite(nsg, oracle, monkeypatch):
     assert float(np.abs(out[1] - ref[1]).max()) <= 2e-2
 
 
+def _e2m3_codes(x):
+    """OCP MX e2m3 (1 sign, 2 exponent, 3 mantissa bits; bias 1; no inf/nan): nearest code, ties to
+    the even code, saturating at 7.5 -- for values already divided by their block scale."""
+    mags = np.array([(c / 8.0) if c < 8 else (1 + (c & 7) / 8.0) * 2.0 ** ((c >> 3) - 1) for c in range(32)])
+    a = np.abs(x).astype(np.float64)
+    hi = np.searchsorted(mags, a, side="left").clip(0, 31)
+    lo = (hi - 1).clip(0, 31)
+    dl, dh = a - mags[lo], mags[hi] - a
+    pick_hi = (dh < dl) | ((dh == dl) & (hi % 2 == 0))
+    code = np.where(pick_hi, hi, lo)
+    code = np.where(a >= 7.5, 31, code)
+    return (code | ((np.signbit(x)).astype(np.int64) << 5)).astype(np.uint8)
+
+
+def test_f16m6_trunk_input_encoding(nsg, oracle):
+    """The plane expansion of an f16m6 evaluator, byte for byte: per (square, 32-channel chunk) a
+    128-byte row [32 x f16 hi][24 B e2m3(hi) + E8M0 exponent][24 B e2m3(lo) + exponent], value j of a
+    block at bits [6j, 6j+6), exponent = that of the block maximum minus 2 (zero block: 2^-17, codes
+    0).  Inputs: real plane bits plus scalar planes with values all over [0, 1]."""
+    B = 70  # an MX plan (two-board tiles need > CUs/4 boards)
+    ev, _ = make(nsg, 1, 256, B, precision="f16m6", seed=3)
+    bb = nsg.synth.random_batch(B, 86, seed=19, garbage=True)
+    ev.upload_features(bb)
+    ev.forward_resident(B)
+    assert ev.last_plan()["trunk_precision"] == "f16m6"
+    raw = ev.download_planes_raw(B)
+    assert raw.shape == (B, 81, 4 * 128)
+    planes = oracle.extract_bits(bb)                                     # [B][86][81] f32
+    x = np.zeros((B, 81, 128), dtype=np.float32)
+    x[:, :, :86] = np.clip(planes.reshape(B, 86, 81).transpose(0, 2, 1), -65000, 65000)
+    rows = raw.reshape(B, 81, 4, 128)
+    hi = rows[..., :64].copy().view(np.float16).reshape(B, 81, 4, 32)
+    want_hi = x.reshape(B, 81, 4, 32).astype(np.float16)
+    np.testing.assert_array_equal(hi.view(np.uint16), want_hi.view(np.uint16))
+    want_lo = (x.reshape(B, 81, 4, 32) - want_hi.astype(np.float32)).astype(np.float16)
+    for name, off, vals in (("hi", 64, want_hi), ("lo", 96, want_lo)):
+        blk = rows[..., off:off + 32]
+        e8 = blk[..., 24].astype(np.int64)
+        assert (blk[..., 25:32] == 0).all()
+        mx = np.abs(vals.astype(np.float64)).max(axis=-1)
+        bits = np.abs(vals).max(axis=-1).astype(np.float16).view(np.uint16).astype(np.int64)
+        np.testing.assert_array_equal(e8, (bits >> 10) + 110, err_msg=name)
+        codes = np.zeros(blk.shape[:-1] + (32,), dtype=np.uint8)
+        words = blk[..., :24].copy().view("<u4").astype(np.uint64).reshape(blk.shape[:-1] + (6,))
+        for j in range(32):
+            w, sh = divmod(6 * j, 32)
+            v = words[..., w] >> np.uint64(sh)
+            if sh > 26:
+                v = v | (words[..., w + 1] << np.uint64(32 - sh))
+            codes[..., j] = (v & np.uint64(63)).astype(np.uint8)
+        scaled = vals.astype(np.float64) / np.exp2(e8 - 127.0)[..., None]
+        want = _e2m3_codes(scaled)
+        same = (codes == want) | ((codes & 31 == 0) & (want & 31 == 0))    # +0 / -0
+        assert same.all(), (name, int((~same).sum()), codes[~same][:8], want[~same][:8])
+        assert mx.max() > 0
+
+
 def test_f16m6_block_scales_follow_the_data(nsg, oracle, monkeypatch):
     """The case test_f16m8_extreme_magnitudes_stay_finite relaxes to 2e-2 -- activations in the
     thousands (BN gamma 512 in the stem) and weights spanning thirteen binades -- in f16m6: its
