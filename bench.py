@@ -230,10 +230,10 @@ def main():
     # BASELINE configs[3]: 256 concurrent games per GPU = 1 thread x 2 groups x 128 games
     # (profiles/r01/h_selfplay_shape_256_games.txt)
     ap.add_argument("--selfplay-threads", type=int, default=1)
-    # host threads advancing the engine's games between two batches: one keeps up in the opening, six are
+    # host threads advancing the engine's games between two batches: one keeps up in the opening, six to eight are
     # needed once positions get busy -- a leaf then costs 10-30 us of move generation and mate search
     # (profiles/r02/a_selfplay_shape_workers.txt, e_selfplay_60s_workers_solvers.txt)
-    ap.add_argument("--selfplay-workers", type=int, default=6)
+    ap.add_argument("--selfplay-workers", type=int, default=8)
     # threads that run the df-pn mate solver of judge (100 000 nodes, worker.cc:516) off the search path
     ap.add_argument("--selfplay-solver-threads", type=int, default=4)
     ap.add_argument("--selfplay-games-per-group", type=int, default=128)
