@@ -683,3 +683,43 @@ def test_load_shared_same_device(nsg, precision):
     d = nsg.Evaluator(0, 8, 86, precision=precision)
     with pytest.raises(nsg.NsgError):
         d.load_shared(c)  # nothing loaded in the source
+
+
+def test_compute_from_a_thread_that_never_bound_the_device(nsg):
+    """Every compute entry binds the evaluator's device itself (the LDS-size attribute of
+    the tile kernels was set for the CALLING thread's current device).  A fresh thread that never
+    called resetGPU drives the evaluator; with a second GPU present, an evaluator on GPU 1 that took
+    its network from GPU 0 by a peer copy (nsg_load_shared) is driven the same way and must return
+    GPU 0's outputs bit for bit."""
+    import threading
+    import torch
+    blob = nsg.weights.to_blob(nsg.weights.make_random(2, 128, seed=91, bn="random"))
+    bb = nsg.synth.random_batch(70, 86, seed=92)
+    a = nsg.Evaluator(0, 70, 86, precision="f16m6")
+    a.load_memory(blob)
+    ref = a.compute_blocking(bb)
+    evs = [a]
+    if torch.cuda.device_count() >= 2:
+        b = nsg.Evaluator(1, 70, 86, precision="f16m6")
+        b.load_shared(a)
+        evs.append(b)
+    got, err = {}, []
+
+    def drive(i, ev):
+        try:
+            got[i] = ev.compute_blocking(bb)          # >64 KiB of LDS per workgroup at this size
+            ev.upload_features(bb)
+            ev.forward_resident(70)
+            got[(i, "resident")] = ev.download_outputs(70)
+        except Exception as e:  # noqa: BLE001
+            err.append(repr(e))
+
+    ts = [threading.Thread(target=drive, args=(i, ev)) for i, ev in enumerate(evs)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not err, err
+    for i in range(len(evs)):
+        for x, y in zip(got[i], ref):
+            np.testing.assert_array_equal(x, y)
+        for x, y in zip(got[(i, "resident")], ref):
+            np.testing.assert_array_equal(x, y)
