@@ -352,14 +352,18 @@ def main():
             sp = {"error": mine.get("error", "the self-play process failed on another rank"), "ranks_failed": int(failed)}
         else:
             sp = dict(tot, **{k: mine[k] for k in ("avg_batch", "cache_hit_ratio", "avg_game_length", "playouts_per_move",
-                                                   "seconds", "window_seconds") if k in mine},
+                                                   "seconds", "window_seconds", "await_ms_per_batch", "host_ms_per_batch",
+                                                   "batches_found_finished") if k in mine},
                       threads_per_gpu=mine.get("threads"), workers_per_thread=mine.get("workers"),
                       solver_threads=mine.get("solver_threads"),
                       note="AlphaZero-mode self-play from startpos on this build's own shogi core; synthetic "
                            "(untrained) weights, so games end early by repetition: games/sec is a plumbing number, "
                            "evals/playouts per sec are the load.  games_per_sec = finished / elapsed from a cold "
                            "start (saveworker.cc:135-137); games_per_sec_window = games finished in the second "
-                           "half of the run / its length (the cold start excluded)")
+                           "half of the run / its length (the cold start excluded).  await_ms_per_batch = engine thread "
+                           "blocked in Infer::await, host_ms_per_batch = its work between two batches, "
+                           "batches_found_finished = share of batches that had already finished when the engine came "
+                           "back for them (0: the executor never waited for the host)")
         barrier()
         ev = None
 

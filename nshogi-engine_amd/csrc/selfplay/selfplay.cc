@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -660,7 +661,10 @@ uint64_t Engine::moveDigest() const {
 
 void Engine::apply(Group& G) {
     if (!G.InFlight) return;
+    const auto T0 = std::chrono::steady_clock::now();
+    if (!G.Ev->isComputing()) ++St.AwaitsIdle;
     G.Ev->await();
+    St.AwaitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - T0).count();
     const std::size_t Games = G.Games.size();
     parallelFor([&](int W) { // every game's results are applied by the worker that owns it
         for (std::size_t K = 0; K < G.Count; ++K) {
@@ -717,8 +721,12 @@ void Engine::collect(Group& G) {
 
 void Engine::step() {
     for (int G = 0; G < 2; ++G) {
+        const uint64_t W0 = St.AwaitNs;
+        const auto T0 = std::chrono::steady_clock::now();
         apply(*Groups[G]);   // results of this group's previous batch
         collect(*Groups[G]); // host search of this group while the other group's batch computes
+        St.HostNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - T0).count() -
+                     (St.AwaitNs - W0);
     }
     const Stats S = stats();
     PubFinished.store(S.finished(), std::memory_order_relaxed);

@@ -93,6 +93,9 @@ struct Stats {
     uint64_t GamesBlack = 0, GamesWhite = 0, GamesDraw = 0;
     uint64_t MovesOfFinishedGames = 0;
     uint64_t TeacherRecords = 0; // positions written by the teacher writer (full-search plies only)
+    uint64_t AwaitNs = 0;        // engine thread blocked in Infer::await (the executor still computing)
+    uint64_t AwaitsIdle = 0;     // ... of which the batch had ALREADY finished: the executor sat idle
+    uint64_t HostNs = 0;         // engine thread applying results and advancing games between two batches
     uint64_t finished() const { return GamesBlack + GamesWhite + GamesDraw; }
 };
 

@@ -209,6 +209,7 @@ int main(int Argc, char* Argv[]) {
         S.GamesWhite += X.GamesWhite; S.GamesDraw += X.GamesDraw;
         S.MovesOfFinishedGames += X.MovesOfFinishedGames; S.MatesFound += X.MatesFound;
         S.TeacherRecords += X.TeacherRecords; S.DfpnMates += X.DfpnMates; S.DfpnNodes += X.DfpnNodes;
+        S.AwaitNs += X.AwaitNs; S.AwaitsIdle += X.AwaitsIdle; S.HostNs += X.HostNs;
         Digest += Engines[E]->moveDigest();
         EvalsPerGpu[(std::size_t)(E / Threads)] += X.Evaluations;
     }
@@ -237,7 +238,11 @@ int main(int Argc, char* Argv[]) {
               << ", \"mate_search\": " << (Opt.MateSearch ? 1 : 0) << ", \"mates_found\": " << S.MatesFound
               << ", \"dfpn_nodes\": " << Opt.DfpnNodes << ", \"dfpn_mates\": " << S.DfpnMates
               << ", \"dfpn_nodes_per_move\": " << (S.Moves ? (double)S.DfpnNodes / S.Moves : 0.0)
-              << ", \"teacher_records\": " << S.TeacherRecords << ", \"evals_per_sec_by_gpu\": [";
+              << ", \"teacher_records\": " << S.TeacherRecords
+              << ", \"await_ms_per_batch\": " << (S.Batches ? S.AwaitNs * 1e-6 / S.Batches : 0.0)
+              << ", \"host_ms_per_batch\": " << (S.Batches ? S.HostNs * 1e-6 / S.Batches : 0.0)
+              << ", \"batches_found_finished\": " << (S.Batches ? (double)S.AwaitsIdle / S.Batches : 0.0)
+              << ", \"evals_per_sec_by_gpu\": [";
     for (int D = 0; D < NumGpus; ++D) std::cout << (D ? ", " : "") << EvalsPerGpu[(std::size_t)D] / Dt;
     std::cout << "], \"digest\": " << Digest << "}" << std::endl;
     return 0;

@@ -10,5 +10,5 @@ PY
 SECS=${SECS:-60}
 for cfg in ${CFGS:-3:4 4:4 6:4 8:4}; do set -- ${cfg/:/ }
   nshogi-engine_amd/csrc/selfplay/selfplay --executor hip --weights /tmp/w.nsgw --gpu 0 --threads 1 --workers $1 --solver-threads $2 --games-per-group 128 --playouts 800 --seconds $SECS --seed 1 --precision 5 |
-    python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('workers $1 solvers $2', {k: round(d[k],2) for k in ('evals_per_sec','playouts_per_sec','moves_per_sec','games_per_sec','games_per_sec_window','avg_batch','cache_hit_ratio','avg_game_length','dfpn_nodes_per_move')}, flush=True)"
+    python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('workers $1 solvers $2', {k: round(d[k],2) for k in ('evals_per_sec','playouts_per_sec','moves_per_sec','games_per_sec','games_per_sec_window','avg_batch','cache_hit_ratio','avg_game_length','dfpn_nodes_per_move','await_ms_per_batch','host_ms_per_batch','batches_found_finished')}, flush=True)"
 done
