@@ -358,7 +358,8 @@ def test_f16m6_block_scales_follow_the_data(nsg, oracle, monkeypatch):
     assert float(np.abs(out[1] - ref[1]).max()) <= 1e-3 and float(np.abs(out[2] - ref[2]).max()) <= 1e-3
 
 
-def test_f16m8_ragged_batch_sizes_against_f16x3(nsg):
+@pytest.mark.parametrize("mx", ["f16m8", "f16m6"])
+def test_f16m8_ragged_batch_sizes_against_f16x3(nsg, mx):
     """Every board of ragged batches on both sides of the plan boundaries (one- and two-board
     tiles, row-split one-board tiles, one and two chains, the f16x3 fallback) against the
     f32-equivalent f16x3 evaluator."""
@@ -370,7 +371,7 @@ def test_f16m8_ragged_batch_sizes_against_f16x3(nsg):
     bmax = max(sizes)
     w = nsg.weights.make_random(1, 256, seed=50, bn="random")
     blob = nsg.weights.to_blob(w)
-    a = nsg.Evaluator(0, bmax, 86, precision="f16m8"); a.load_memory(blob)
+    a = nsg.Evaluator(0, bmax, 86, precision=mx); a.load_memory(blob)
     b = nsg.Evaluator(0, bmax, 86, precision="f16x3"); b.load_memory(blob)
     bb = nsg.synth.random_batch(bmax, 86, seed=51)
     seen = set()
@@ -382,7 +383,7 @@ def test_f16m8_ragged_batch_sizes_against_f16x3(nsg):
         assert np.isfinite(pa).all()
         assert float(np.abs(pa - pb).max()) < TOL, (n, plan)
         assert float(np.abs(va - vb).max()) < TOL and float(np.abs(da - db).max()) < TOL
-    assert ("f16m8", 1, 1) in seen and ("f16m8", 2, 1) in seen and ("f16m8", 2, 2) in seen, seen
+    assert (mx, 1, 1) in seen and (mx, 2, 1) in seen and (mx, 2, 2) in seen, seen
 
 
 @pytest.mark.parametrize("precision", ["f16m8", "f16x3"])
