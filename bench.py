@@ -473,6 +473,9 @@ def main():
                     by_batch[str(nb)] = rate
                 by_batch["512"] = value
                 out["evals_per_sec_by_batch"] = by_batch
+                # ... and as a fraction of the MFMA roofline (north_star: "as absolute numbers and as fraction
+                # of the MFMA roofline"): evals/s x algorithmic flops per position / the f16 dense peak
+                out["frac_of_mfma_roofline_by_batch"] = {k: v * flops_pos / 1e12 / peak for k, v in by_batch.items()}
                 big.close()
             out["roofline_extract"] = extract_roofline(nsg, bb, B)
         if not args.no_host_path and world == 1:
