@@ -311,8 +311,12 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1>
 __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
     using G = Geom<MODE, SIZE, NWAVES, (isMx(PREC) ? (KS > 1 ? 8 : 4) : 2)>;
-    static_assert(KS == 1 || (isMx(PREC) && MODE == kConv && SIZE == 1 && MS == 1 && NWAVES % KS == 0),
+    static_assert(KS == 1 || (isMx(PREC) && MODE == kConv && SIZE == 1 && NWAVES % KS == 0),
                   "K split: kF16m8 one-board conv tiles");
+    // K split AND row split: the row groups are separate WORKGROUPS (blockIdx.z), each with all its waves on
+    // the K parts -- eight workgroups per board for the smallest batches, whose layers are a latency chain
+    // (the main loop of a four-way K split is 17k of its 30k cycles: half the rows, half of that)
+    constexpr bool kRowWG = (MS > 1 && KS > 1);
     const bool hasRes = (RES == 1) || (RES == 2 && A.res != nullptr);
     NSG_STAMP_DECL
     NSG_STAMP(0);
@@ -322,7 +326,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     constexpr bool kSplit = (PREC == kF16x3);
     static_assert(!kM8 || (MODE == kConv && NFRAG == 4), "kF16m8: full trunk-conv tiles only");
     static_assert(NFRAG == 1 || NFRAG == 2 || NFRAG == 4, "fragments per wave");
-    static_assert(MS == 1 || (MODE == kConv && SIZE == 1 && G::kMF % MS == 0 && NWAVES % MS == 0 &&
+    static_assert(MS == 1 || (MODE == kConv && SIZE == 1 && G::kMF % MS == 0 && (KS > 1 || NWAVES % MS == 0) &&
                               (NFRAG < 4 || isMx(PREC))),
                   "row split: one-board conv tiles (small tiles, or kF16m8 full-channel tiles)");
     constexpr int kMFw = G::kMF / MS; // row fragments this wave computes
@@ -345,8 +349,11 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         nkc = per;
     }
     const int nft = A.cout / 16;
-    const int waveGroup = (blockIdx.y * NWAVES + wave) / (MS * KS); // group of NFRAG channel fragments
-    const int fBase = (MS > 1) ? (wave % MS) * kMFw : 0;     // first row fragment of this wave
+    const int waveGroup = (blockIdx.y * NWAVES + wave) / (kRowWG ? KS : MS * KS); // group of NFRAG channel fragments
+    const int fBase = (MS > 1) ? (kRowWG ? (int)blockIdx.z : wave % MS) * kMFw : 0; // first row fragment of this wave
+    // rows this workgroup may write (a K part past the workgroup's last fragment adds up and converts
+    // whatever lies there: with the rows split over workgroups those rows belong to the next one)
+    const int rowLimit = kRowWG ? ((fBase + kMFw) * 16 < G::kRows ? (fBase + kMFw) * 16 : G::kRows) : G::kRows;
     // kConv buffers are sized for whole workgroups; flat modes clamp rows.
     const size_t lastRow = G::kBoards ? ~(size_t)0 : (size_t)(A.totalRows - 1);
 
@@ -1000,7 +1007,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                 for (int it = 0; it < kIPF; ++it) {
                     const int m = (fBaseE + f) * 16 + it * kRPI + lrow;
                     rpre[f][it] = u32x4{0u, 0u, 0u, 0u};
-                    if (__builtin_expect(m < G::kRows, 1))
+                    if (__builtin_expect(m < rowLimit, 1))
                         rpre[f][it] = *reinterpret_cast<const u32x4*>(resBase + (size_t)(NSG_RES_FRAG(f) * 16 + it * kRPI) * rowBytes + laneOff);
                 }
         }
@@ -1034,7 +1041,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     if (f < kPreFrags) {
                         t = rpre[f < kPreFrags ? f : 0][it];
                     } else {
-                        if (__builtin_expect(m < G::kRows, 1))
+                        if (__builtin_expect(m < rowLimit, 1))
                             t = *reinterpret_cast<const u32x4*>(resBase + (size_t)(NSG_RES_FRAG(f) * 16 + it * kRPI) * rowBytes + laneOff);
                     }
                     *reinterpret_cast<u32x4*>(ebuf + (f % kRegions) * kFragBytes + r * kRowS + lpc * 16) = t;
@@ -1245,7 +1252,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
                     const int m = (fBaseE + f) * 16 + it * kRPI + lrow;
-                    if (__builtin_expect(m < G::kRows, 1))
+                    if (__builtin_expect(m < rowLimit, 1))
                         *reinterpret_cast<u32x4*>(yBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff) = tt[it];
                 }
             }
@@ -1351,8 +1358,10 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int MS = 1, int KS = 1>
 hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
     using G = Geom<MODE, SIZE, NWAVES, (isMx(PREC) ? (KS > 1 ? 8 : 4) : 2)>;
-    const int gy = a.cout / (NWAVES / (MS * KS) * NFRAG * 16);
-    if (gy < 1 || gy * (NWAVES / (MS * KS)) * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
+    constexpr bool kRowWG = (MS > 1 && KS > 1); // row groups as workgroups (grid z), see tileBody
+    constexpr int kChanGroups = NWAVES / (kRowWG ? KS : MS * KS);
+    const int gy = a.cout / (kChanGroups * NFRAG * 16);
+    if (gy < 1 || gy * kChanGroups * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
     if (KS > 1) { // every chunk tile resident: at most eight, and whole pairs for every K part
         const int chunks = a.kdim * 4 / 128;
         if (chunks > 8 || chunks % (2 * KS) != 0) return hipErrorInvalidValue;
@@ -1368,7 +1377,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
             if (err != hipSuccess) return err;
             attrDevMask.fetch_or(1 << dev);
         }
-        hipLaunchKernelGGL(k, dim3(gridX, gy), dim3(G::kThreads), G::kLdsAlloc, stream, a.x, a.w, a.res, a.y, a.bias,
+        hipLaunchKernelGGL(k, dim3(gridX, gy, kRowWG ? MS : 1), dim3(G::kThreads), G::kLdsAlloc, stream, a.x, a.w, a.res, a.y, a.bias,
                            a.kdim, a.cout, (a.relu ? 1 : 0) | (a.outF16x3 ? 2 : 0), a.accScale, tailOf(a));
     } else {
         auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false, MS, KS>;
@@ -1380,7 +1389,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
             if (err != hipSuccess) return err;
             attrDevMask.fetch_or(1 << dev);
         }
-        hipLaunchKernelGGL(k, dim3(gridX, gy, MODE == kDense ? a.kSplits : 1), dim3(G::kThreads), G::kLdsAlloc, stream,
+        hipLaunchKernelGGL(k, dim3(gridX, gy, MODE == kDense ? a.kSplits : (kRowWG ? MS : 1)), dim3(G::kThreads), G::kLdsAlloc, stream,
                            a.x, a.w, a.res, a.y, a.bias, a.kdim, a.cout, (a.relu ? 1 : 0) | (a.outF16x3 ? 2 : 0), a.accScale, tailOf(a));
     }
     return hipGetLastError();

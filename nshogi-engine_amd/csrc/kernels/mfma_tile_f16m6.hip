@@ -13,6 +13,10 @@ hipError_t launchConvF16m6(const Args& a, int batch, const ConvPlan& p, hipStrea
     if (p.ksplit == 4 && p.nb == 1 && p.nwaves == 4) {
         // small batches: four K quarters on one 64-channel group (four workgroups per board); a layer with
         // fewer than four chunk pairs (the stem) runs the two-halves kernel
+        // ... and for the very smallest batches each of those workgroups is two: one per half of the rows
+        if ((a.kdim / 32) % 8 == 0 && p.msplit == 2) return launchOne<kF16m6, kConv, 1, 4, 4, 2, 4>(a, gx, s);
+        if ((a.kdim / 32) % 8 == 0 && p.msplit == 3) return launchOne<kF16m6, kConv, 1, 4, 4, 3, 4>(a, gx, s);
+        if ((a.kdim / 32) % 8 == 0 && p.msplit == 6) return launchOne<kF16m6, kConv, 1, 4, 4, 6, 4>(a, gx, s);
         if ((a.kdim / 32) % 8 == 0) return launchOne<kF16m6, kConv, 1, 4, 4, 1, 4>(a, gx, s);
         return launchOne<kF16m6, kConv, 1, 4, 4, 1, 2>(a, gx, s);
     }

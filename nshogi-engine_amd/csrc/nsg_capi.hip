@@ -513,6 +513,15 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
             // small batches: four workgroups per board, each one 64-channel group whose four waves take one chunk
             // pair apiece (K split by four, whole board resident in LDS)
             plan.nb = 1; plan.nfrag = 4; plan.nwaves = 4; plan.msplit = 1; plan.ksplit = 4;
+            // ... and while eight workgroups per board still fit the chip in one round, the rows are split
+            // over two workgroups as well (NSG_ROWSPLIT8_MAX_BATCH, read when the evaluator is created)
+            // -- two, three or six row groups of three, two or one fragment: as many as fit the chip in one round
+            const int k8max = ev->tuning.rowsplit8Max;
+            if (k8max >= 0 ? B <= k8max : true) {
+                if ((long)B * 24 <= cus) plan.msplit = 6;
+                else if ((long)B * 12 <= cus) plan.msplit = 3;
+                else if ((long)B * 8 <= cus) plan.msplit = 2;
+            }
         } else
         if (wgM8 <= cus && wgM8 * 2 > cus) { // (measured: 1.17-1.29 ms for every B in 65..128; kF16x3 plans 1.26-1.54 ms)
             plan.nb = 1; plan.nfrag = 4; plan.nwaves = 4; plan.msplit = 2;
@@ -709,7 +718,8 @@ static int checkTuningEnv() {
         {"NSG_CONV_NFRAG", 1, 4, "fragments per wave (1, 2 or 4)"}, {"NSG_CONV_MSPLIT", 1, 2, "row split"},
         {"NSG_CHAINS", 1, nsg_evaluator::kMaxChains, "half-batch chains"}, {"NSG_TRUNK_KERNEL", 0, 1, "persistent trunk"},
         {"NSG_CHAIN_DELAY_US", -1, 1000000, "chain stagger"}, {"NSG_CHAIN_MIN_BATCH", 2, 65535, "smallest chained batch"},
-        {"NSG_KSPLIT4_MAX_BATCH", 0, 65535, "largest batch of the four-way K split"}, {"NSG_ROCTX", 0, 1, "profiler markers"}};
+        {"NSG_KSPLIT4_MAX_BATCH", 0, 65535, "largest batch of the four-way K split"},
+        {"NSG_ROWSPLIT8_MAX_BATCH", 0, 65535, "largest batch of the four-way K split with two row groups"}, {"NSG_ROCTX", 0, 1, "profiler markers"}};
     for (const Var& v : vars) {
         const char* e = getenv(v.name);
         if (!e) continue;

@@ -180,7 +180,7 @@ def test_load_device_blob_matches_load_memory(nsg):
 
 @pytest.mark.parametrize("mx", ["f16m8", "f16m6"])
 @pytest.mark.parametrize("channels,batch,ksplit", [(256, 70, 2), (256, 101, 2), (256, 128, 2), (128, 200, 2),
-                                                   (256, 1, 4), (256, 7, 4), (256, 40, 4), (256, 64, 4)])
+                                                   (256, 1, 4), (256, 7, 4), (256, 19, 4), (256, 32, 4), (256, 40, 4), (256, 64, 4)])
 def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch, ksplit, mx):
     """One-board kF16m8 tiles split by K, the whole board resident in eight LDS image buffers.
     Mid batches (one workgroup per board and 128 output channels fills more than half the CUs): the
@@ -202,7 +202,10 @@ def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch, ksplit, 
     bb = nsg.synth.random_batch(batch, 86, seed=64, garbage=True)
     p, v, d = ev.compute_blocking(bb)
     plan = ev.last_plan()
-    assert plan["trunk_precision"] == mx and plan["boards_per_group"] == 1 and plan["k_split"] == ksplit and plan["row_split"] == 1
+    # the smallest batches split the rows of a four-way K split over two workgroups as well (eight per board)
+    rows8 = ksplit == 4 and batch * 8 <= cus
+    assert plan["trunk_precision"] == mx and plan["boards_per_group"] == 1 and plan["k_split"] == ksplit
+    assert plan["row_split"] == (6 if batch * 24 <= cus else 3 if batch * 12 <= cus else 2 if rows8 else 1)
     idx = sorted({0, batch // 2, batch - 1})
     check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
     x3, _ = make(nsg, 3, channels, bmax, precision="f16x3", seed=63)
@@ -215,6 +218,15 @@ def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch, ksplit, 
         plan = rows.last_plan()
         assert plan["row_split"] == 2 and plan["k_split"] == 1
         assert float(np.abs(p - pr).max()) < 3e-4 and float(np.abs(v - vr).max()) < 1e-4 and float(np.abs(d - dr).max()) < 1e-4
+    if rows8:  # row fragments are independent: four workgroups per board give the same bits as eight
+        monkeypatch.setenv("NSG_ROWSPLIT8_MAX_BATCH", "0")
+        four, _ = make(nsg, 3, channels, bmax, precision=mx, seed=63)
+        p4, v4, d4 = four.compute_blocking(bb)
+        plan = four.last_plan()
+        assert plan["row_split"] == 1 and plan["k_split"] == 4
+        np.testing.assert_array_equal(p4, p)
+        np.testing.assert_array_equal(v4, v)
+        np.testing.assert_array_equal(d4, d)
     # a forward is deterministic: the same bits again, also at another slot of the batch
     p2, v2, d2 = ev.compute_blocking(bb[::-1].copy())
     np.testing.assert_array_equal(p2[::-1], p)
