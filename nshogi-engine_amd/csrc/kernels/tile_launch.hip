@@ -16,6 +16,7 @@ ConvTuning readConvTuning() {
     if (const char* e = getenv("NSG_CONV_NFRAG")) t.nfrag = atoi(e);
     if (const char* e = getenv("NSG_CONV_MSPLIT")) t.msplit = atoi(e);
     if (const char* e = getenv("NSG_ROWSPLIT8_MAX_BATCH")) t.rowsplit8Max = atoi(e);
+    if (const char* e = getenv("NSG_SPLIT_BATCH")) t.splitBatch = atoi(e);
     return t;
 }
 

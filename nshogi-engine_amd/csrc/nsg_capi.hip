@@ -486,12 +486,8 @@ int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& pla
     return NSG_OK;
 }
 
-int enqueueForward(nsg_evaluator* ev, size_t n) {
-    const int B = (int)n;
-    ++ev->statBatches;
-    ev->statPositions += n;
-    hipStream_t s = ev->stream;
-    // the tile plan is chosen for the whole batch: all chains run concurrently
+// The tile plan of a batch of B boards on this evaluator (precision, channel count, CU count, tuning).
+nsg::ConvPlan planForBatch(nsg_evaluator* ev, int B) {
     nsg::ConvPlan plan = nsg::chooseConvPlan(B, ev->F, ev->prop.multiProcessorCount, ev->tuning);
     // kF16m8 keeps four image buffers in LDS (125 KB for two boards): a CU holds one two-board
     // workgroup, so where the channel count only allows two-wave workgroups (F = 384) one-board
@@ -535,6 +531,17 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         }
     }
 
+    return plan;
+}
+
+int enqueueForward(nsg_evaluator* ev, size_t n) {
+    const int B = (int)n;
+    ++ev->statBatches;
+    ev->statPositions += n;
+    hipStream_t s = ev->stream;
+    // the tile plan is chosen for the whole batch: all chains run concurrently
+    nsg::ConvPlan plan = planForBatch(ev, B);
+    const bool mx = nsg::isMx(ev->prec) && !ev->W->outsideM8Window;
     const bool prof = ev->profile;
     if (prof && ev->evUsed + 4 > (int)ev->ev.size()) {
         int rc = drainProfile(ev);
@@ -569,6 +576,36 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     ev->lastPlan = plan;
     ev->lastChains = chains;
 
+    // Two-part batches.  Between the sizes whose plans fill the chip exactly, one plan for the whole batch leaves
+    // CUs idle (B = CUs/2 + 1 .. CUs as one-board tiles: one workgroup per board) or pays a two-board tile for a
+    // half-empty chip (B = CUs + 1 ..).  Boards never interact, so such a batch runs as a FULL part with the plan of
+    // the size below (CUs/2 boards, two-way K split; CUs boards, one-board tiles) plus the remainder with ITS plan
+    // (up to CUs/4 boards: the K split by four), on two streams like the half-batch chains above.
+    int firstPart = 0;
+    if (mx && chains == 1 && !trunkKernel && ev->numChains >= 2 && ev->tuning.splitBatch != 0 && ev->F == 256 &&
+        ev->cpad == 128 && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 && ev->tuning.nwaves == 0 && ev->tuning.msplit == 0) {
+        // (measured on 256 CUs, profiles/r02/n_ab_two_part_batches.txt: 129 +10.6 %, 144 +7.7 %, 168 +5.7 %, 176 +2.5 %,
+        // 192 -5.9 %; 257 +52 %, 288 +37 %, 320 +27 %, 352 +18 %, 368 +14 %, 384 -7 %: from 3/2 of the CUs on
+        // the two-board tiles cover three quarters of the chip and win)
+        if (B > cus / 2 && B <= cus / 2 + 3 * cus / 16) firstPart = cus / 2;
+        else if (B > cus && B < cus + cus / 2) firstPart = cus;
+    }
+    if (firstPart > 0) {
+        const nsg::ConvPlan planA = planForBatch(ev, firstPart), planB = planForBatch(ev, B - firstPart);
+        ev->lastPlan = planA;
+        ev->lastChains = 2;
+        hipStream_t cs = ev->chainStream[0];
+        NSG_HIP(hipEventRecord(ev->forkEvent, s));
+        if (prof) NSG_HIP(hipEventRecord(e[1], s));
+        NSG_HIP(hipStreamWaitEvent(cs, ev->forkEvent, 0));
+        int rc = enqueueChain(ev, 0, firstPart, planA, s, true);
+        if (rc) return rc;
+        rc = enqueueChain(ev, firstPart, B - firstPart, planB, cs, false);
+        if (rc) return rc;
+        NSG_HIP(hipEventRecord(ev->joinEvent[0], cs));
+        NSG_HIP(hipStreamWaitEvent(s, ev->joinEvent[0], 0));
+        if (prof) NSG_HIP(hipEventRecord(e[2], s));
+    } else
     if (chains == 1 && trunkKernel) {
         // one persistent launch for all 2N+1 3x3 layers (measured slower; NSG_TRUNK_KERNEL=1)
         const int prec = ev->prec;
@@ -719,7 +756,8 @@ static int checkTuningEnv() {
         {"NSG_CHAINS", 1, nsg_evaluator::kMaxChains, "half-batch chains"}, {"NSG_TRUNK_KERNEL", 0, 1, "persistent trunk"},
         {"NSG_CHAIN_DELAY_US", -1, 1000000, "chain stagger"}, {"NSG_CHAIN_MIN_BATCH", 2, 65535, "smallest chained batch"},
         {"NSG_KSPLIT4_MAX_BATCH", 0, 65535, "largest batch of the four-way K split"},
-        {"NSG_ROWSPLIT8_MAX_BATCH", 0, 65535, "largest batch of the four-way K split with two row groups"}, {"NSG_ROCTX", 0, 1, "profiler markers"}};
+        {"NSG_ROWSPLIT8_MAX_BATCH", 0, 65535, "largest batch of the four-way K split with two row groups"},
+        {"NSG_SPLIT_BATCH", 0, 1, "full part + remainder batches"}, {"NSG_ROCTX", 0, 1, "profiler markers"}};
     for (const Var& v : vars) {
         const char* e = getenv(v.name);
         if (!e) continue;

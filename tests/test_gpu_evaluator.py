@@ -427,6 +427,7 @@ def test_f16m8_persistent_trunk_kernel_bit_identical(nsg, monkeypatch, mx):
     """NSG_TRUNK_KERNEL=1: all 3x3 layers in one launch (a workgroup owns its boards through every
     layer, no grid barrier).  Same arithmetic, so bit-identical to per-layer launches."""
     bb = nsg.synth.random_batch(300, 86, seed=79)
+    monkeypatch.setenv("NSG_SPLIT_BATCH", "0")  # one plan for the whole batch on both sides (300 = CUs + 44 would run as two parts)
     monkeypatch.setenv("NSG_TRUNK_KERNEL", "0")
     ev, _ = make(nsg, 3, 256, 300, precision=mx, seed=34)
     p, v, d = ev.compute_blocking(bb)
@@ -736,3 +737,39 @@ def test_compute_from_a_thread_that_never_bound_the_device(nsg):
             np.testing.assert_array_equal(x, y)
         for x, y in zip(got[(i, "resident")], ref):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("mx", ["f16m8", "f16m6"])
+def test_two_part_batches(nsg, oracle, monkeypatch, mx):
+    """Between the batch sizes whose plans fill the chip exactly, a batch runs as a full part with the
+    plan of the size below plus the remainder with its own plan, on two streams (CUs/2 + r boards:
+    two-way K split + the small-batch plan of r; CUs + r: one-board tiles + r).  Against the oracle,
+    against the f16x3 evaluator on every board, and against the one-plan run (NSG_SPLIT_BATCH=0:
+    other summation orders, same arithmetic)."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    sizes = [cus // 2 + 1, cus // 2 + 23, cus // 2 + 3 * cus // 16, cus + 5, cus + cus // 4, cus + cus // 2 - 1]
+    bmax = cus + cus // 2
+    ev, blob = make(nsg, 2, 256, bmax, precision=mx, seed=71)
+    x3, _ = make(nsg, 2, 256, bmax, precision="f16x3", seed=71)
+    monkeypatch.setenv("NSG_SPLIT_BATCH", "0")
+    one, _ = make(nsg, 2, 256, bmax, precision=mx, seed=71)
+    bb = nsg.synth.random_batch(bmax, 86, seed=72, garbage=True)
+    net = oracle.net(blob)
+    for n in sizes:
+        p, v, d = ev.compute_blocking(bb[:n])
+        assert ev.last_plan()["chains"] == 2 and ev.last_plan()["trunk_precision"] == mx, (n, ev.last_plan())
+        p1, v1, d1 = one.compute_blocking(bb[:n])
+        assert one.last_plan()["chains"] == 1
+        p3, v3, d3 = x3.compute_blocking(bb[:n])
+        assert float(np.abs(p - p3).max()) < TOL and float(np.abs(v - v3).max()) < TOL and float(np.abs(d - d3).max()) < TOL
+        assert float(np.abs(p - p1).max()) < 5e-4 and float(np.abs(v - v1).max()) < 2e-4
+        first = cus // 2 if n <= cus else cus
+        idx = [0, first - 1, first, n - 1]
+        check((p[idx], v[idx], d[idx]), net.evaluate(bb[idx]), TOL)
+    # one board more than the ranges: a single plan again
+    ev.compute_blocking(bb[: cus // 2 + 3 * cus // 16 + 1])
+    assert ev.last_plan()["chains"] == 1
+    ev.compute_blocking(bb[: cus + cus // 2])
+    assert ev.last_plan()["chains"] == 1
