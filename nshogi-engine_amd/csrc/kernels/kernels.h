@@ -90,6 +90,7 @@ constexpr int kNfrag = 4; // every packed tensor uses 4 fragments (64 channels) 
 struct ConvTuning {
     int nb = 0, nwaves = 0, nfrag = 0, msplit = 0; // msplit: NSG_CONV_MSPLIT (1 = never split rows)
     int splitBatch = 1;    // NSG_SPLIT_BATCH=0: never run a batch as a full part + remainder
+    int splitBatchMax3 = 9;  // NSG_SPLIT_BATCH_MAX: largest batch, in quarters of the CU count, that starts with a full chip of two-board tiles
     int rowsplit8Max = -1; // NSG_ROWSPLIT8_MAX_BATCH: largest batch whose four-way K split also splits the rows over two workgroups (-1: CUs / 8)
     bool fullTilesOnly = false; // kF16m8: 4 fragments per wave at every batch size
 };

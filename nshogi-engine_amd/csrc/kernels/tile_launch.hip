@@ -17,6 +17,7 @@ ConvTuning readConvTuning() {
     if (const char* e = getenv("NSG_CONV_MSPLIT")) t.msplit = atoi(e);
     if (const char* e = getenv("NSG_ROWSPLIT8_MAX_BATCH")) t.rowsplit8Max = atoi(e);
     if (const char* e = getenv("NSG_SPLIT_BATCH")) t.splitBatch = atoi(e);
+    if (const char* e = getenv("NSG_SPLIT_BATCH_MAX")) t.splitBatchMax3 = atoi(e);
     return t;
 }
 

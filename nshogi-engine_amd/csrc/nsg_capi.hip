@@ -581,29 +581,41 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // half-empty chip (B = CUs + 1 ..).  Boards never interact, so such a batch runs as a FULL part with the plan of
     // the size below (CUs/2 boards, two-way K split; CUs boards, one-board tiles) plus the remainder with ITS plan
     // (up to CUs/4 boards: the K split by four), on two streams like the half-batch chains above.
-    int firstPart = 0;
-    if (mx && chains == 1 && !trunkKernel && ev->numChains >= 2 && ev->tuning.splitBatch != 0 && ev->F == 256 &&
-        ev->cpad == 128 && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 && ev->tuning.nwaves == 0 && ev->tuning.msplit == 0) {
+    struct Part { int off, count; nsg::ConvPlan plan; };
+    Part parts[3];
+    int nParts = 0;
+    if (mx && !trunkKernel && ev->numChains >= 2 && ev->tuning.splitBatch != 0 && ev->F == 256 && ev->cpad == 128 &&
+        ev->tuning.nb == 0 && ev->tuning.nfrag == 0 && ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 &&
+        ev->chainMinBatch <= 0 && ev->chainDelayUs == 0) {
         // (measured on 256 CUs, profiles/r02/n_ab_two_part_batches.txt: 129 +10.6 %, 144 +7.7 %, 168 +5.7 %, 176 +2.5 %,
         // 192 -5.9 %; 257 +52 %, 288 +37 %, 320 +27 %, 352 +18 %, 368 +14 %, 384 -7 %: from 3/2 of the CUs on
         // the two-board tiles cover three quarters of the chip and win)
-        if (B > cus / 2 && B <= cus / 2 + 3 * cus / 16) firstPart = cus / 2;
-        else if (B > cus && B < cus + cus / 2) firstPart = cus;
+        int off = 0, rem = B;
+        auto take = [&](int count) { parts[nParts++] = Part{off, count, planForBatch(ev, count)}; off += count; rem -= count; };
+        // more two-board tiles than CUs: one full chip of them first, the rest by the rules below (instead of two
+        // half-batch chains; only just above 2 CUs boards: 513-576 +2-3.5 %, from 640 on the two chains are 3-11 %
+        // faster, profiles/r02/n_ab_two_part_batches.txt)
+        if (rem > 2 * cus && rem <= ev->tuning.splitBatchMax3 * cus / 4) take(2 * cus);
+        if (rem > cus && rem < cus + cus / 2) take(cus);
+        else if (rem > cus / 2 && rem <= cus / 2 + 3 * cus / 16) take(cus / 2);
+        if (nParts > 0 && rem > 0) take(rem);
+        if (nParts < 2) nParts = 0;
     }
-    if (firstPart > 0) {
-        const nsg::ConvPlan planA = planForBatch(ev, firstPart), planB = planForBatch(ev, B - firstPart);
-        ev->lastPlan = planA;
-        ev->lastChains = 2;
-        hipStream_t cs = ev->chainStream[0];
+    if (nParts > 0) {
+        ev->lastPlan = parts[0].plan;
+        ev->lastChains = nParts;
         NSG_HIP(hipEventRecord(ev->forkEvent, s));
         if (prof) NSG_HIP(hipEventRecord(e[1], s));
-        NSG_HIP(hipStreamWaitEvent(cs, ev->forkEvent, 0));
-        int rc = enqueueChain(ev, 0, firstPart, planA, s, true);
-        if (rc) return rc;
-        rc = enqueueChain(ev, firstPart, B - firstPart, planB, cs, false);
-        if (rc) return rc;
-        NSG_HIP(hipEventRecord(ev->joinEvent[0], cs));
-        NSG_HIP(hipStreamWaitEvent(s, ev->joinEvent[0], 0));
+        for (int c = 0; c < nParts; ++c) {
+            hipStream_t cs = (c == 0) ? s : ev->chainStream[c - 1];
+            if (c > 0) NSG_HIP(hipStreamWaitEvent(cs, ev->forkEvent, 0));
+            int rc = enqueueChain(ev, parts[c].off, parts[c].count, parts[c].plan, cs, c == 0);
+            if (rc) return rc;
+            if (c > 0) {
+                NSG_HIP(hipEventRecord(ev->joinEvent[c - 1], cs));
+                NSG_HIP(hipStreamWaitEvent(s, ev->joinEvent[c - 1], 0));
+            }
+        }
         if (prof) NSG_HIP(hipEventRecord(e[2], s));
     } else
     if (chains == 1 && trunkKernel) {
@@ -757,7 +769,8 @@ static int checkTuningEnv() {
         {"NSG_CHAIN_DELAY_US", -1, 1000000, "chain stagger"}, {"NSG_CHAIN_MIN_BATCH", 2, 65535, "smallest chained batch"},
         {"NSG_KSPLIT4_MAX_BATCH", 0, 65535, "largest batch of the four-way K split"},
         {"NSG_ROWSPLIT8_MAX_BATCH", 0, 65535, "largest batch of the four-way K split with two row groups"},
-        {"NSG_SPLIT_BATCH", 0, 1, "full part + remainder batches"}, {"NSG_ROCTX", 0, 1, "profiler markers"}};
+        {"NSG_SPLIT_BATCH", 0, 1, "full part + remainder batches"},
+        {"NSG_SPLIT_BATCH_MAX", 0, 64, "largest batch (quarters of the CU count) that starts with a full chip of two-board tiles"}, {"NSG_ROCTX", 0, 1, "profiler markers"}};
     for (const Var& v : vars) {
         const char* e = getenv(v.name);
         if (!e) continue;
