@@ -251,13 +251,17 @@ int nsg_get_stats(nsg_evaluator* ev, uint64_t* batches, uint64_t* positions);
 
 /* Launch plan of the most recent forward pass (tests and tuning): boards per
  * workgroup, 16-channel fragments per wave, waves per workgroup, and the number
- * of independent half-batch chains.  All zero before the first forward pass. */
+ * of independent launch chains the batch ran as -- half-batch chains of one
+ * plan (more tiles than CUs), or a full part plus remainder parts with their own
+ * plans (batch sizes just above the ones a plan fills the chip at; the reported
+ * plan is the first part's).  All zero before the first forward pass. */
 int nsg_get_last_plan(nsg_evaluator* ev, int* boards_per_group, int* fragments_per_wave,
                       int* waves_per_group, int* chains);
 /* How the waves of one channel group shared a one-board tile in the most recent forward pass:
  * row_split waves took disjoint row fragments (small tiles), or k_split waves took disjoint ranges
- * of the input channels for all rows and summed their accumulators (F16M8 at small and mid batches).  1 / 1
- * for ordinary tiles, 0 / 0 before the first pass. */
+ * of the input channels for all rows and summed their accumulators (F16M8 / F16M6 at small and mid batches);
+ * with k_split = 4 a row_split of 2, 3 or 6 means that many WORKGROUPS per channel group, each on its
+ * share of the rows (the smallest batches).  1 / 1 for ordinary tiles, 0 / 0 before the first pass. */
 int nsg_get_last_split(nsg_evaluator* ev, int* row_split, int* k_split);
 /* Arithmetic the most recent forward pass ran its trunk in (NSG_PRECISION_*; -1 before
  * the first pass).  An F16M8 evaluator runs small batches for which it has no F16M8 tile plan
