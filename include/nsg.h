@@ -11,8 +11,12 @@
  *
  * Threading contract (same as the reference): one evaluator
  * per evaluation thread, at most one batch in flight per evaluator, not
- * thread-safe per object, no global mutable state.  Results in the Dst*
- * buffers are defined only after nsg_await() returns.
+ * thread-safe per object, no global mutable state in the HIP evaluator (one
+ * exception below it, kept on purpose: the CPU stand-in Random executor shares
+ * ONE function-static distribution object across all its instances, exactly as
+ * random.cc:32 does -- a uniform_real_distribution<float> keeps no state between
+ * draws with libstdc++, so outputs depend on each object's own engine only).
+ * Results in the Dst* buffers are defined only after nsg_await() returns.
  *
  * All functions return NSG_OK (0) on success or a negative NSG_E_* code;
  * nsg_last_error() returns a thread-local description of the last failure.
