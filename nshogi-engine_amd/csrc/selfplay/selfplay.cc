@@ -65,6 +65,8 @@ class Game {
  public:
     // Slot: this game slot's number among the run's Stride concurrent slots; its k-th game has id Slot + k * Stride
     Game(Engine* E, Engine::WorkerCtx* C, uint64_t Slot, uint64_t Stride) : Eng(E), Ctx(C), GameId(Slot), Stride(Stride) { newGame(false); }
+    // the host thread about to advance this game lends it its counters, solver and cache scratch
+    void bind(Engine::WorkerCtx* C) { Ctx = C; }
     Game(const Game&) = delete;
     Game& operator=(const Game&) = delete;
 
@@ -512,7 +514,7 @@ class Game {
     Move SolverMove;
     uint64_t SolverNodes = 0;
     Engine* Eng;
-    Engine::WorkerCtx* Ctx; // the worker that owns this game slot
+    Engine::WorkerCtx* Ctx; // the worker advancing this game right now (bind)
     uint64_t GameId; // of the game being played: slot + k * Stride
     uint64_t Stride;
     Arena Tree;
@@ -539,7 +541,8 @@ struct Engine::Group {
     std::vector<std::unique_ptr<Game>> Games;
     std::unique_ptr<evaluate::Evaluator> Ev;
     std::vector<int> Pending;
-    std::vector<std::size_t> Counts; // leaves found per worker in the last collect
+    std::vector<uint8_t> Has;        // collect: game I produced a leaf
+    std::unique_ptr<std::atomic<std::size_t>[]> Cursor; // per worker range: next item to take (work stealing)
     std::size_t Count = 0;
     bool InFlight = false;
 };
@@ -568,7 +571,8 @@ Engine::Engine(infer::Infer* Exec0, infer::Infer* Exec1, const Options& O, uint6
         Groups[G]->Ev = std::make_unique<evaluate::Evaluator>(EngineIndex * 2 + G, shogi::NumFeaturePlanes,
                                                               (std::size_t)Opt.GamesPerGroup, Exec[G], PinMemory);
         Groups[G]->Pending.resize(Opt.GamesPerGroup);
-        Groups[G]->Counts.assign((std::size_t)Opt.Workers, 0);
+        Groups[G]->Has.assign((std::size_t)Opt.GamesPerGroup, 0);
+        Groups[G]->Cursor = std::make_unique<std::atomic<std::size_t>[]>((std::size_t)Opt.Workers);
         for (int I = 0; I < Opt.GamesPerGroup; ++I)
             Groups[G]->Games.push_back(std::make_unique<Game>(
                 this, Ctx[(std::size_t)ownerOf((std::size_t)I, (std::size_t)Opt.GamesPerGroup)].get(),
@@ -665,13 +669,22 @@ void Engine::apply(Group& G) {
     if (!G.Ev->isComputing()) ++St.AwaitsIdle;
     G.Ev->await();
     St.AwaitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - T0).count();
-    const std::size_t Games = G.Games.size();
-    parallelFor([&](int W) { // every game's results are applied by the worker that owns it
-        for (std::size_t K = 0; K < G.Count; ++K) {
-            const std::size_t I = (std::size_t)G.Pending[K];
-            if (ownerOf(I, Games) != W) continue;
-            G.Games[I]->setEvaluation(G.Ev->getPolicy() + K * shogi::MoveIndexMax, G.Ev->getWinRate()[K],
-                                      G.Ev->getDrawRate()[K]);
+    // (the pending list is in game order: worker w starts on its share of it, the same games it will
+    // advance first in the next collect, and helps with the other shares when it is done)
+    const std::size_t W = (std::size_t)Opt.Workers, Cnt = G.Count;
+    for (std::size_t Wk = 0; Wk < W; ++Wk) G.Cursor[Wk].store(Cnt * Wk / W, std::memory_order_relaxed);
+    parallelFor([&](int Me) {
+        WorkerCtx* Mine = Ctx[(std::size_t)Me].get();
+        for (std::size_t Step = 0; Step < W; ++Step) {
+            const std::size_t Wk = ((std::size_t)Me + Step) % W;
+            const std::size_t Hi = Cnt * (Wk + 1) / W;
+            for (;;) {
+                const std::size_t K = G.Cursor[Wk].fetch_add(1, std::memory_order_relaxed);
+                if (K >= Hi) break;
+                Game& Gm = *G.Games[(std::size_t)G.Pending[K]];
+                Gm.bind(Mine);
+                Gm.setEvaluation(G.Ev->getPolicy() + K * shogi::MoveIndexMax, G.Ev->getWinRate()[K], G.Ev->getDrawRate()[K]);
+            }
         }
     });
     G.InFlight = false;
@@ -681,27 +694,34 @@ void Engine::collect(Group& G) {
     static_assert(sizeof(FeaturePlane) == sizeof(ml::FeatureBitboard), "feature plane layout");
     auto* Slots = reinterpret_cast<FeaturePlane*>(G.Ev->getFeatureBitboards());
     const std::size_t Games = G.Games.size(), W = (std::size_t)Opt.Workers;
-    // worker w advances its own games and packs their leaves from slot lo(w) on
-    parallelFor([&](int Wk) {
-        const std::size_t Lo = Games * (std::size_t)Wk / W, Hi = Games * ((std::size_t)Wk + 1) / W;
-        std::size_t N = 0;
-        for (std::size_t I = Lo; I < Hi; ++I) {
-            if (G.Games[I]->advanceUntilEvaluation(Slots + (Lo + N) * shogi::NumFeaturePlanes)) {
-                G.Pending[Lo + N++] = (int)I;
+    // Worker w advances the games of its own range first (their trees are warm in its caches), then
+    // takes games from the other ranges until none is left: a leaf costs anything between a cache hit
+    // and a three-ply mate search, and with fixed ranges every batch waited for the unluckiest worker.
+    // Which thread advances a game changes nothing in it (counters and digests are sums).  A game's
+    // planes go to the slot of its own index; the gaps (a game parked on the mate solver) are closed
+    // afterwards, so the batch order is the game order whatever the threads did.
+    for (std::size_t Wk = 0; Wk < W; ++Wk) G.Cursor[Wk].store(Games * Wk / W, std::memory_order_relaxed);
+    parallelFor([&](int Me) {
+        WorkerCtx* Mine = Ctx[(std::size_t)Me].get();
+        for (std::size_t Step = 0; Step < W; ++Step) {
+            const std::size_t Wk = ((std::size_t)Me + Step) % W;
+            const std::size_t Hi = Games * (Wk + 1) / W;
+            for (;;) {
+                const std::size_t I = G.Cursor[Wk].fetch_add(1, std::memory_order_relaxed);
+                if (I >= Hi) break;
+                Game& Gm = *G.Games[I];
+                Gm.bind(Mine);
+                G.Has[I] = Gm.advanceUntilEvaluation(Slots + I * shogi::NumFeaturePlanes) ? 1 : 0;
             }
         }
-        G.Counts[(std::size_t)Wk] = N;
     });
-    // close the gaps a worker left (a game that found nothing to evaluate: rare)
     std::size_t N = 0;
-    for (std::size_t Wk = 0; Wk < W; ++Wk) {
-        const std::size_t Lo = Games * Wk / W, C = G.Counts[Wk];
-        if (Lo != N && C) {
-            std::memmove(Slots + N * shogi::NumFeaturePlanes, Slots + Lo * shogi::NumFeaturePlanes,
-                         C * shogi::NumFeaturePlanes * sizeof(FeaturePlane));
-            std::memmove(&G.Pending[N], &G.Pending[Lo], C * sizeof(int));
-        }
-        N += C;
+    for (std::size_t I = 0; I < Games; ++I) {
+        if (!G.Has[I]) continue;
+        if (I != N)
+            std::memcpy(Slots + N * shogi::NumFeaturePlanes, Slots + I * shogi::NumFeaturePlanes,
+                        shogi::NumFeaturePlanes * sizeof(FeaturePlane));
+        G.Pending[N++] = (int)I;
     }
     G.Count = N;
     if (N == 0) return;

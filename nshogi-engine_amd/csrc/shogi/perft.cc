@@ -66,10 +66,14 @@ int main(int Argc, char** Argv) {
             for (int Ply = 0; Ply < 300; ++Ply) {
                 MoveList L;
                 S.generateLegalMoves(L);
+                if (S.hasLegalMove() != (L.size() > 0)) { std::cout << "hasLegalMove mismatch at " << S.toSfen() << std::endl; return 1; }
                 if (L.size() == 0 || S.repetitionStatus(true) != NoRepetition) break;
                 const uint64_t H = S.hash();
-                for (const Move& M : L) { // givesCheck vs make-the-move-and-look
+                State::CheckInfo CI;
+                S.checkInfo(CI);
+                for (const Move& M : L) { // givesCheck vs make-the-move-and-look, and the per-position table vs both
                     const bool Quick = S.givesCheck(M);
+                    if (S.givesCheck(M, CI) != Quick) { std::cout << "check table mismatch at " << S.toSfen() << " move " << moveToUsi(M) << std::endl; return 1; }
                     S.doMove(M);
                     const bool Slow = S.inCheck();
                     S.undoMove();

@@ -232,6 +232,17 @@ inline void pushMoves(MoveList& Out, Color Us, int From, int To, PieceType T, Pi
 } // namespace
 
 void State::generateLegalMoves(MoveList& Out) const {
+    genLegal<false>(Out);
+}
+
+bool State::hasLegalMove() const {
+    MoveList Out; // at most one or two entries are written before the generator returns
+    return genLegal<true>(Out);
+}
+
+// AnyOnly: return true as soon as one legal move exists (nothing useful is left in Out).
+template <bool AnyOnly>
+bool State::genLegal(MoveList& Out) const {
     Out.Size = 0;
     const Color Us = Side, Them = ~Side;
     const int K = KingSq[Us];
@@ -298,7 +309,8 @@ void State::generateLegalMoves(MoveList& Out) const {
         if (attackedWithout(To, Them, K, -1)) continue;
         Out.push(Move::make(K, To, false, King, typeOf(P)));
     }
-    if (NumCheckers >= 2) return;
+    if (AnyOnly && Out.Size > 0) return true;
+    if (NumCheckers >= 2) return Out.Size > 0;
 
     const bool InCheck = NumCheckers == 1;
     for (int S2 = 0; S2 < NumSquares; ++S2) Ctx.Target[S2] = !InCheck || Between[S2] || S2 == CheckerSq;
@@ -320,13 +332,15 @@ void State::generateLegalMoves(MoveList& Out) const {
                 if ((Q && colorOf(Q) == Us) || !Ctx.Target[To]) continue;
                 pushMoves(Out, Us, From, To, T, typeOf(Q));
             }
+            if (AnyOnly && Out.Size > 0) return true;
             continue;
         }
         const uint8_t Steps = stepMask(P), Slides = slideMask(P);
         for (int D = 0; D < 8; ++D) {
             const uint8_t Bit = (uint8_t)(1u << D);
             if (!((Steps | Slides) & Bit)) continue;
-            if (Pin >= 0 && (D & 3) != (Pin & 3)) continue; // only along the pin line
+            if (AnyOnly && Out.Size > 0) return true;
+        if (Pin >= 0 && (D & 3) != (Pin & 3)) continue; // only along the pin line
             int F = FF + kDF[D], R = FR + kDR[D];
             while (onBoard(F, R)) {
                 const int To = makeSquare(F, R);
@@ -343,11 +357,12 @@ void State::generateLegalMoves(MoveList& Out) const {
     // ---- drops
     bool HaveHand = false;
     for (int T = Pawn; T <= Gold; ++T) HaveHand |= Hands[Us][T] != 0;
-    if (!HaveHand) return;
+    if (AnyOnly && Out.Size > 0) return true;
+    if (!HaveHand) return Out.Size > 0;
     if (InCheck) {
         bool Any = false;
         for (int S2 = 0; S2 < NumSquares; ++S2) Any |= Between[S2];
-        if (!Any) return; // contact or knight check: a drop cannot help
+        if (!Any) return Out.Size > 0; // contact or knight check: a drop cannot help
     }
     bool PawnOnFile[9] = {false};
     if (Hands[Us][Pawn])
@@ -370,8 +385,10 @@ void State::generateLegalMoves(MoveList& Out) const {
                     continue; // uchifuzume
             }
             Out.push(Move::makeDrop((PieceType)T, To));
+            if (AnyOnly) return true;
         }
     }
+    return Out.Size > 0;
 }
 
 // A pawn dropped on `To` checks the enemy king.  It is an illegal "drop pawn mate"
@@ -386,9 +403,7 @@ bool State::isPawnDropMate(int To) const {
     Tmp.put(To, makePiece(Side, Pawn));
     --Tmp.Hands[Side][Pawn];
     Tmp.Side = ~Side;
-    MoveList Replies;
-    Tmp.generateLegalMoves(Replies);
-    return Replies.size() == 0;
+    return !Tmp.hasLegalMove();
 }
 
 void State::generatePseudo(MoveList& Out) const {
@@ -649,6 +664,44 @@ bool State::givesCheck(Move M) const {
     return false;
 }
 
+void State::checkInfo(CheckInfo& CI) const {
+    const int K = KingSq[~Side], KF = fileOf(K), KR = rankOf(K);
+    std::memset(CI.RayDir, -1, sizeof(CI.RayDir));
+    std::memset(CI.Adjacent, 0, sizeof(CI.Adjacent));
+    std::memset(CI.OnLine, 0, sizeof(CI.OnLine));
+    for (int D = 0; D < 8; ++D) {
+        bool Seen = true, First = true;
+        for (int F = KF + kDF[D], R = KR + kDR[D]; onBoard(F, R); F += kDF[D], R += kDR[D]) {
+            const int S2 = makeSquare(F, R);
+            CI.OnLine[S2] = true;
+            if (Seen) {
+                CI.RayDir[S2] = (int8_t)D;
+                CI.Adjacent[S2] = First;
+                if (Board[S2]) Seen = false; // the first occupied square is still a landing square (a capture)
+            }
+            First = false;
+        }
+    }
+    // a knight of the side to move on (KF -+ 1, KR - 2*forward(Us)) attacks the king
+    const int NR = KR - 2 * forward(Side);
+    CI.KnightSq[0] = onBoard(KF - 1, NR) ? makeSquare(KF - 1, NR) : -1;
+    CI.KnightSq[1] = onBoard(KF + 1, NR) ? makeSquare(KF + 1, NR) : -1;
+}
+
+bool State::givesCheck(Move M, const CheckInfo& CI) const {
+    // a piece that leaves one of the king's lines may discover a check, or slide along the line: exact test
+    if (!M.isDrop() && CI.OnLine[M.from()]) return givesCheck(M);
+    const int To = M.to();
+    const PieceType T = M.promote() ? promote(M.moved()) : M.moved();
+    if (T == Knight) return To == CI.KnightSq[0] || To == CI.KnightSq[1];
+    const int D = CI.RayDir[To];
+    if (D < 0) return false;
+    // (the squares between the king and To are empty now and stay empty: From is not on this ray)
+    const Piece P = makePiece(Side, T);
+    const uint8_t Back = (uint8_t)(1u << ((D + 4) & 7)); // direction from To toward the king
+    return (slideMask(P) & Back) || (CI.Adjacent[To] && (stepMask(P) & Back));
+}
+
 // A square the king of `Defender` can step to safely (empty or enemy-occupied, not attacked once the king
 // has left its square), or -1.  The cheap way to see that a check is not mate: most checks leave one.
 int State::kingFlight(Color Defender) const {
@@ -673,15 +726,15 @@ Move State::findMateInOneQuick() {
     MoveList Pseudo;
     generatePseudo(Pseudo);
     const Color Us = Side;
+    CheckInfo CI;
+    checkInfo(CI);
     for (const Move& M : Pseudo) {
-        if (!givesCheck(M)) continue;
+        if (!givesCheck(M, CI)) continue;
         if (M.isDrop() && M.moved() == Pawn) continue;
         doMove(M);
         bool Mate = false;
         if (!isAttacked(KingSq[Us], ~Us) && kingFlight(~Us) < 0) { // a legal move, and the king cannot just step away
-            MoveList Replies;
-            generateLegalMoves(Replies);
-            Mate = Replies.size() == 0;
+            Mate = !hasLegalMove();
         }
         undoMove();
         if (Mate) return M;
@@ -701,8 +754,10 @@ Move State::findMate(int Depth, bool Prefilter, const MoveList* Legal) {
     Move Checks[600];
     int8_t Flight[600];
     int NumChecks = 0;
+    CheckInfo CI;
+    if (Prefilter) checkInfo(CI);
     for (const Move& M : Moves) {
-        if (Prefilter && !givesCheck(M)) continue;
+        if (Prefilter && !givesCheck(M, CI)) continue;
         doMove(M);
         if (!inCheck()) { // (after the move the side to move is the defender; only reached without the prefilter)
             undoMove();
@@ -710,11 +765,7 @@ Move State::findMate(int Depth, bool Prefilter, const MoveList* Legal) {
         }
         const int Fl = Prefilter ? kingFlight(Side) : -1;
         int NumReplies = 1;
-        if (Fl < 0) {
-            MoveList Replies;
-            generateLegalMoves(Replies);
-            NumReplies = Replies.size();
-        }
+        if (Fl < 0) NumReplies = hasLegalMove() ? 1 : 0;
         undoMove();
         if (NumReplies == 0) return M; // drop-pawn mate is not a legal move, so M is a real mate
         Flight[NumChecks] = (int8_t)Fl;

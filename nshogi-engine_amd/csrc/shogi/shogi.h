@@ -108,6 +108,9 @@ class State {
 
     // Legal moves (pins, checks, nifu, dead-square drops and drop-pawn-mate excluded).
     void generateLegalMoves(MoveList& Out) const;
+    // Does the side to move have any legal move?  The same generator, stopping at the first move
+    // (the mate search only asks whether a checked side has a reply at all).
+    bool hasLegalMove() const;
     // Independent slow generator: pseudo-legal + make/unmake king test (cross-check).
     void generateLegalMovesSlow(MoveList& Out);
 
@@ -133,6 +136,20 @@ class State {
     // Does this legal move of the side to move give check (directly or by discovery)?  Exact,
     // from the current position, without making the move.
     bool givesCheck(Move M) const;
+    // The squares from which the enemy king can be checked, worked out once per position for the
+    // many givesCheck questions of a mate search: RayDir[sq] = direction (0..7) of the ray from the
+    // king on which sq is visible (through empty squares; the first occupied square included), or -1;
+    // Adjacent[sq]: one step from the king; OnLine[sq]: on one of the king's eight lines at all, seen or
+    // not (a piece leaving such a square may discover a check or slide along the line: those moves take
+    // the exact test); KnightSq: where a knight of the side to move would check.
+    struct CheckInfo {
+        int8_t RayDir[NumSquares];
+        bool Adjacent[NumSquares];
+        bool OnLine[NumSquares];
+        int KnightSq[2];
+    };
+    void checkInfo(CheckInfo& CI) const;
+    bool givesCheck(Move M, const CheckInfo& CI) const; // == givesCheck(M)
 
     uint64_t perft(int Depth);
 
@@ -148,6 +165,7 @@ class State {
     void put(int Sq, Piece P);
     void remove(int Sq);
     void generatePseudo(MoveList& Out) const;
+    template <bool AnyOnly> bool genLegal(MoveList& Out) const;
 
     Piece Board[NumSquares];
     uint8_t Hands[2][8];
