@@ -758,8 +758,8 @@ void Engine::drain() {
     for (int G = 0; G < 2; ++G) apply(*Groups[G]);
 }
 
-void Engine::run(const volatile bool* Stop, uint64_t MaxFinishedGames) {
-    while (!*Stop && (MaxFinishedGames == 0 || stats().finished() < MaxFinishedGames)) step();
+void Engine::run(const std::atomic<bool>* Stop, uint64_t MaxFinishedGames) {
+    while (!Stop->load(std::memory_order_relaxed) && (MaxFinishedGames == 0 || stats().finished() < MaxFinishedGames)) step();
     drain();
 }
 

@@ -131,7 +131,7 @@ class Engine {
     ~Engine();
 
     // Runs until `Stop` becomes true or `MaxFinishedGames` games have finished (0 = no limit).
-    void run(const volatile bool* Stop, uint64_t MaxFinishedGames);
+    void run(const std::atomic<bool>* Stop, uint64_t MaxFinishedGames);
     // Single-step variant for tests: advance both groups once.
     void step();
     void drain(); // await in-flight batches and apply them

@@ -163,7 +163,7 @@ int main(int Argc, char* Argv[]) {
     std::vector<std::unique_ptr<selfplay::Engine>> Engines((std::size_t)NumEngines);
     std::atomic<int> Built{0}, Running{NumEngines};
     std::atomic<bool> Go{false};
-    volatile bool Stop = false;
+    std::atomic<bool> Stop{false};
     std::vector<std::thread> Workers;
     const uint64_t PerEngineGames = MaxGames ? (MaxGames + NumEngines - 1) / NumEngines : 0;
     for (int E = 0; E < NumEngines; ++E) {

@@ -66,7 +66,9 @@ const char* kSfenPiece = " PLNSBRGK";
 
 } // namespace
 
-uint64_t State::SideKey = 0;
+// (set once, before main: every State reads it, none writes it -- it used to be assigned in fromSfen, a
+// benign but real data race once several host threads parsed positions)
+uint64_t State::SideKey = zob().Side;
 
 void State::put(int Sq, Piece P) {
     Board[Sq] = P;
@@ -129,7 +131,6 @@ State State::fromSfen(const std::string& Sfen) {
         }
     }
     S.PlyOffset = Ply - 1;
-    SideKey = zob().Side;
     return S;
 }
 
