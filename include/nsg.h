@@ -82,8 +82,13 @@ int nsg_create(int gpu_id, int batch_size_max, int num_channels,
 int nsg_destroy(nsg_evaluator* ev);
 
 /* Selects the trunk arithmetic (NSG_PRECISION_*).  Must be called before
- * nsg_load*; default NSG_PRECISION_FP32.  (The reference fixes this at
- * engine-build time through BuilderFlag::kTF32, src/infer/trt.cc:160-161.) */
+ * nsg_load*.  An evaluator starts with NSG_PRECISION_FP32 unless the
+ * environment variable NSG_PRECISION (0..5, or fp32 fp16 bf16 f16x3 f16m8
+ * f16m6; anything else makes nsg_create fail) names another default -- so an
+ * engine whose executor ladder only constructs and loads
+ * can be run at the benchmarked arithmetic, NSG_PRECISION=f16m6, unchanged.
+ * (The reference fixes this at engine-build time through BuilderFlag::kTF32,
+ * src/infer/trt.cc:160-161.) */
 int nsg_set_precision(nsg_evaluator* ev, int precision);
 
 /* Replaces infer::TensorRT::load(const std::string& Path, bool) --

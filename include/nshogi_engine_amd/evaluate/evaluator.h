@@ -19,6 +19,9 @@
 
 #include "../infer/infer.h"
 #include "../../nsg.h"
+#if __has_include(<nshogi/ml/common.h>)
+#include <nshogi/ml/common.h> // ml::MoveIndexMax (as src/evaluate/evaluator.h:19)
+#endif
 
 #include <sched.h>
 

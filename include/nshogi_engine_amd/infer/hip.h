@@ -41,7 +41,10 @@ class Hip : public Infer {
     Hip(const Hip&) = delete;
     Hip& operator=(const Hip&) = delete;
 
-    // NSG_PRECISION_FP32 (default, exact f32 MFMA), _FP16 or _BF16.
+    // One of NSG_PRECISION_FP32 (exact f32 MFMA; what a new evaluator starts with unless the
+    // environment variable NSG_PRECISION names another default), _F16X3 (f32-equivalent split f16),
+    // _F16M6 (split f16 with fp6 MX correction terms: 1.5e-4 from a CPU fp32 executor, 5x the f32
+    // rate -- the recommended setting and what bench.py measures), _F16M8, _FP16, _BF16 (nsg.h).
     // Plays the role of BuilderFlag::kTF32 (trt.cc:160-161); call before load().
     void setPrecision(int Precision) {
         check(nsg_set_precision(Handle, Precision));

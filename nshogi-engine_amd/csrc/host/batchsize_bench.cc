@@ -4,19 +4,24 @@
 // Evaluator::computeBlocking(BatchSize) calls (H2D + planes + net + D2H + sync),
 // prints "BatchSize, ms, evals/s".
 //
-// usage: batchsize_bench <weights.nsgw> [repeat=1000] [first=60] [last=159]
-//                        [precision=0|1|2] [executor=hip|zero|nothing|random]
-// The feature planes replicated across the batch are synthetic (seeded): the
-// start position's planes need libnshogi, which is not available here.
+// usage: batchsize_bench <model.onnx|weights.nsgw> [repeat=1000] [first=60] [last=159]
+//                        [precision=0..5|env] [executor=hip|zero|nothing|random]
+// precision: an NSG_PRECISION_* number (0 fp32, 1 fp16, 2 bf16, 3 f16x3, 4 f16m8, 5 f16m6) or
+// "env" (default): no setPrecision call, exactly what the engine's ladder does -- the evaluator
+// then starts with NSG_PRECISION from the environment (nsg.h), fp32 if unset.
+// Every slot holds the INITIAL POSITION's 86 planes, like the reference
+// (batchsize.cc:47-59: StateBuilder::getInitialState() -> FeatureType), built by this
+// repository's rules core (csrc/shogi/features.cc).
 #include <nshogi_engine_amd/evaluate/evaluator.h>
 #include <nshogi_engine_amd/infer/cpu.h>
 #include <nshogi_engine_amd/infer/hip.h>
+
+#include "../shogi/features.h"
 
 #include <chrono>
 #include <cstring>
 #include <iostream>
 #include <memory>
-#include <random>
 #include <string>
 #include <vector>
 
@@ -24,26 +29,16 @@ using namespace nshogi;
 using namespace nshogi::engine;
 
 namespace {
-constexpr std::size_t kFeatureSize = 86; // global_config::FeatureType::size()
+constexpr std::size_t kFeatureSize = shogi::NumFeaturePlanes; // global_config::FeatureType::size()
 
-std::vector<ml::FeatureBitboard> syntheticPosition() {
-    std::mt19937_64 Mt(20240203); // src/test/test_extractbit.cc:72
+std::vector<ml::FeatureBitboard> initialPosition() {
+    static_assert(sizeof(shogi::FeaturePlane) == sizeof(ml::FeatureBitboard), "one 16-byte layout");
+    const shogi::State State; // the initial position
+    const shogi::StateConfig Config;
+    std::vector<shogi::FeaturePlane> Planes(kFeatureSize);
+    shogi::buildFeatures(State, Config, Planes.data());
     std::vector<ml::FeatureBitboard> FS(kFeatureSize);
-    for (std::size_t C = 0; C < kFeatureSize; ++C) {
-        uint64_t Lo = 0, Hi = 0;
-        if (C < 28) { // sparse piece planes
-            for (int K = 0; K < 4; ++K) {
-                const unsigned Sq = (unsigned)(Mt() % 81);
-                if (Sq < 63) Lo |= 1ULL << Sq; else Hi |= 1ULL << (Sq - 63);
-            }
-        } else if (Mt() % 3 == 0) { // hand / colour planes: all squares or none
-            Lo = (1ULL << 63) - 1;
-            Hi = (1ULL << 18) - 1;
-        }
-        Hi |= 0x3f800000ULL << 32; // value 1.0f
-        FS[C].Lo = Lo;
-        FS[C].Hi = Hi;
-    }
+    std::memcpy(static_cast<void*>(FS.data()), Planes.data(), kFeatureSize * sizeof(ml::FeatureBitboard));
     return FS;
 }
 } // namespace
@@ -58,19 +53,25 @@ int main(int Argc, char* Argv[]) {
     const std::size_t Repeat = Argc > 2 ? std::stoul(Argv[2]) : 1000;
     const unsigned First = Argc > 3 ? std::stoul(Argv[3]) : 60;
     const unsigned Last = Argc > 4 ? std::stoul(Argv[4]) : 159;
-    const int Precision = Argc > 5 ? std::stoi(Argv[5]) : NSG_PRECISION_FP32;
+    const std::string PrecisionArg = Argc > 5 ? Argv[5] : "env";
     const std::string Executor = Argc > 6 ? Argv[6] : "hip";
 
     std::cout << "Bench batch size for the weight file " << WeightPath << " with " << Repeat
               << " repeats." << std::endl;
-    const auto FeatureStack = syntheticPosition();
+    const auto FeatureStack = initialPosition();
 
     for (unsigned BatchSize = First; BatchSize <= Last; ++BatchSize) {
         std::unique_ptr<infer::Infer> Infer;
         if (Executor == "hip") {
             auto H = std::make_unique<infer::Hip>(0, (uint16_t)BatchSize, (uint16_t)kFeatureSize);
-            H->setPrecision(Precision);
+            if (PrecisionArg != "env") H->setPrecision(std::stoi(PrecisionArg));
             H->load(WeightPath, false);
+            if (BatchSize == First) {
+                nsg_info Info;
+                nsg_get_info(H->handle(), &Info);
+                std::cout << "# executor hip on " << Info.device_name << ", precision " << Info.precision
+                          << ", " << Info.blocks << "x" << Info.channels << std::endl;
+            }
             Infer = std::move(H);
         } else if (Executor == "zero") {
             Infer = std::make_unique<infer::Zero>();

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <strings.h>
 
 #include <algorithm>
 #include <atomic>
@@ -782,10 +783,29 @@ static int checkTuningEnv() {
     return NSG_OK;
 }
 
+// NSG_PRECISION: the arithmetic an evaluator starts with when the caller never calls
+// nsg_set_precision -- the engine's executor ladders construct, load and run, so
+// this is how an unmodified ladder reaches the benchmarked arithmetic.  A number 0..5 or a name.
+static int precisionFromEnv(int* prec) {
+    const char* e = getenv("NSG_PRECISION");
+    if (!e || !*e) return NSG_OK;
+    static const char* const names[] = {"fp32", "fp16", "bf16", "f16x3", "f16m8", "f16m6"};
+    for (int i = 0; i <= NSG_PRECISION_F16M6; ++i) {
+        const char digit[2] = {(char)('0' + i), 0};
+        if (!strcasecmp(e, names[i]) || !strcmp(e, digit)) {
+            *prec = i;
+            return NSG_OK;
+        }
+    }
+    return fail(NSG_E_INVALID, "NSG_PRECISION=%s: expected 0..5 or one of fp32 fp16 bf16 f16x3 f16m8 f16m6", e);
+}
+
 int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator** out) {
     if (!out) return fail(NSG_E_INVALID, "null out pointer");
     *out = nullptr;
     if (int trc = checkTuningEnv()) return trc;
+    int envPrec = NSG_PRECISION_FP32;
+    if (int prc = precisionFromEnv(&envPrec)) return prc;
     if (batch_size_max <= 0 || batch_size_max > 65535 || num_channels <= 0 || num_channels > 1024)
         return fail(NSG_E_INVALID, "bad batch_size_max/num_channels");
     int count = 0;
@@ -798,6 +818,7 @@ int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator**
     ev->gpu = gpu_id;
     ev->batchMax = batch_size_max;
     ev->numChannels = num_channels;
+    ev->prec = envPrec;
     NSG_HIP(hipSetDevice(gpu_id));
     NSG_HIP(hipGetDeviceProperties(&ev->prop, gpu_id));
     int rc;

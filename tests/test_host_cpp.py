@@ -74,12 +74,35 @@ def test_batchsize_bench_runs(nsg, tmp_path):
     _build()
     path = tmp_path / "net.nsgw"
     nsg.weights.save(str(path), nsg.weights.make_random(2, 64, seed=1))
-    r = subprocess.run([os.path.join(HOST, "batchsize_bench"), str(path), "20", "60", "62"],
-                       capture_output=True, text=True, timeout=600)
+    # no precision argument and no setPrecision call -- what the engine's ladder does
+    # (INTEGRATION.md 1): NSG_PRECISION in the environment picks the arithmetic
+    for env_prec, want in ((None, 0), ("f16m6", 5), ("3", 3)):
+        env = dict(os.environ)
+        env.pop("NSG_PRECISION", None)
+        if env_prec is not None:
+            env["NSG_PRECISION"] = env_prec
+        r = subprocess.run([os.path.join(HOST, "batchsize_bench"), str(path), "20", "60", "62"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().split("\n")
+        assert f"precision {want}," in lines[1], lines[1]
+        rows = [ln.split(",") for ln in lines[2:]]
+        assert [int(x[0]) for x in rows] == [60, 61, 62]
+        assert all(float(x[2]) > 0 for x in rows)
+    env["NSG_PRECISION"] = "tf32"
+    r = subprocess.run([os.path.join(HOST, "batchsize_bench"), str(path), "20", "60", "60"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "NSG_PRECISION=tf32" in r.stderr
+
+
+def test_batchsize_bench_random_executor_initial_position(nsg, tmp_path):
+    """EXECUTOR=random through the same harness on the CPU (BASELINE configs[0] plumbing)."""
+    _build()
+    r = subprocess.run([os.path.join(HOST, "batchsize_bench"), "none", "3", "5", "6", "env", "random"],
+                       capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     rows = [ln.split(",") for ln in r.stdout.strip().split("\n")[1:]]
-    assert [int(x[0]) for x in rows] == [60, 61, 62]
-    assert all(float(x[2]) > 0 for x in rows)
+    assert [int(x[0]) for x in rows] == [5, 6]
 
 
 @pytest.mark.parametrize("cfg", ["5000 4 64 4 2 2", "3000 8 7 3 1 0", "2000 1 512 3 2 4", "8000 6 33 5 3 3"])
