@@ -19,7 +19,13 @@ One process per GPU; positions shard across ranks with no data-path collective
 (weak scaling); RCCL is used once, to broadcast the weight blob from rank 0.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (what the driver runs)
+    python bench.py --gpus N ...     without a launcher: this process starts the N ranks itself
+                                     (torch.distributed.run as a CHILD process) and relays their line;
+                                     it fails loudly when the machine has fewer than N GPUs
+`--gpus` must equal WORLD_SIZE when a launcher set one; the line carries `ranks_seen` (an all-reduce of 1).
+`--executor random` is the CPU rehearsal of the multi-rank path (gloo, the reference's EXECUTOR=random
+stand-in as the executor, no GPU touched): tests/test_bench_launcher.py drives it with 2 ranks.
 """
 import argparse
 import importlib
@@ -49,10 +55,39 @@ DTYPE_NAME = {"fp32": "f32", "fp16": "f16", "bf16": "bf16", "f16x3": "f16x3 (spl
 MFMA_UNITS = {"fp32": 1, "fp16": 1, "bf16": 1, "f16x3": 3, "f16m8": 2.0, "f16m6": 1.5}
 
 
-def cpu_baseline(seconds=12.0):
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def _physical_cores_available():
+    """Physical cores this process may run on: distinct (package, core) pairs among its affinity mask."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+    seen = set()
+    for c in cpus:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            seen.add(("?", str(c)))
+    return max(1, len(seen))
+
+
+def cpu_baseline(seconds=8.0, all_cores_seconds=6.0, max_threads=16):
     """The reference's EXECUTOR=random CPU path (src/infer/random.cc:28-42 driven
-    like src/bench/batchsize.cc) via the oracle restatement ("port"), one core,
-    batch 512, bounded to ~`seconds` of CPU work."""
+    like src/bench/batchsize.cc) via the oracle restatement ("port"), batch 512, bounded to
+    ~`seconds` of CPU work: (i) one core -- what one reference evaluation thread does;
+    (ii) SURVEY.md 8d (ii): one Random + buffer pair per thread on T threads at once (T = the
+    physical cores this process may use, capped at `max_threads`: a one-GPU box's CPU share is 16)."""
+    import threading
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     o = oracle_lib.load()
@@ -63,17 +98,34 @@ def cpu_baseline(seconds=12.0):
         o.random_compute(st, 512)
         n += 512
     dt = time.perf_counter() - t0
-    model = ""
-    try:
-        for ln in open("/proc/cpuinfo"):
-            if ln.startswith("model name"):
-                model = ln.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": f"infer::Random(0) restatement, batch 512, {n} positions in {dt:.1f} s on 1 of "
-                      f"{os.cpu_count()} host cores ({model})"}
+    model = _cpu_model()
+    out = {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+           "sample": f"infer::Random(0) restatement, batch 512, {n} positions in {dt:.1f} s on 1 of "
+                     f"{os.cpu_count()} host cores ({model})"}
+    phys = _physical_cores_available()
+    T = max(1, min(phys, max_threads))
+    counts = [0] * T
+    stop = time.perf_counter() + all_cores_seconds
+
+    def work(i):  # ctypes releases the GIL inside the oracle call: the threads run in parallel
+        mine = o.mt(i)
+        while time.perf_counter() < stop:
+            o.random_compute(mine, 512)
+            counts[i] += 512
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    out["all_cores"] = {"value": sum(counts) / dt, "unit": "evals/s", "cores": T, "kind": "port",
+                        "physical_cores_available": phys, "host_threads_total": os.cpu_count(),
+                        "sample": f"{T} threads, one infer::Random(seed i) restatement + output buffers each, batch 512, "
+                                  f"{sum(counts)} positions in {dt:.1f} s ({model}); T = physical cores available to this "
+                                  f"process capped at {max_threads} (the CPU share of a one-GPU box)"}
+    return out
 
 
 def pmc_summary(args, B):
@@ -82,7 +134,7 @@ def pmc_summary(args, B):
     this run: PMC collection needs its own rocprofv3 passes; the bench line names the file."""
     if args.net != "20x256" or B != 512:
         return None, None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         rel = os.path.join("profiles", rnd, f"pmc_{args.precision}_summary.json")
         try:
             return json.load(open(os.path.join(ROOT, rel))), rel
@@ -212,6 +264,113 @@ def selfplay_cpu_baseline(seconds=8.0):
     return json.loads(r.stdout.strip().split("\n")[-1]) if r.returncode == 0 else None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) under
+    torch.distributed.run as a CHILD process, relay the one JSON line rank 0 prints, return the child's
+    exit code.  This process never initialises the GPU (torch.cuda.device_count() only counts)."""
+    import subprocess
+    if args.executor == "hip":
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this machine has {have} GPU(s): refusing to report a "
+                  f"{args.gpus}-GPU number from fewer devices", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout[-2000:])
+        print(f"bench.py: the {args.gpus}-rank run failed (exit {r.returncode})", file=sys.stderr)
+        return r.returncode or 1
+    line = json.loads(lines[-1])
+    if line.get("ranks_seen") != args.gpus or line.get("n_gpus") != args.gpus:
+        print(f"bench.py: asked for {args.gpus} ranks, the line reports n_gpus={line.get('n_gpus')} "
+              f"ranks_seen={line.get('ranks_seen')}", file=sys.stderr)
+        return 3
+    line["launched_by"] = "bench.py itself (torch.distributed.run as a child process)"
+    print(json.dumps(line))
+    return 0
+
+
+def rehearse_cpu(args, rank, world):
+    """--executor random: the multi-rank skeleton of this file on the CPU -- gloo process group, weight-blob
+    broadcast from rank 0, per-rank executor, barrier-bracketed K steps, max over ranks, ranks_seen -- with
+    the reference's CPU stand-in executor (src/infer/random.cc via nsg_cpu_executor) in the evaluator's place."""
+    import torch.distributed as dist
+    nsg = importlib.import_module("nshogi-engine_amd")
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group(backend="gloo")
+    blocks, channels = (int(x) for x in args.net.split("x"))
+    blob = nsg.weights.to_blob(nsg.weights.make_random(1, 64, seed=0)) if rank == 0 else None
+    blob_bytes = len(blob) if blob is not None else 0
+    if distributed:
+        got = nsg.dist.broadcast_blob(blob, src=0, device="cpu")
+        blob_bytes = int(got.numel())
+    ranks_seen = int(nsg.dist.sum_over_ranks(1.0)) if distributed else 1
+    B = args.batch
+    ex = nsg.CpuExecutor("random", seed=nsg.dist.shard_seed(0, rank))
+    pol = np.empty((B, 2187), np.float32)
+    win = np.empty(B, np.float32)
+    drw = np.empty(B, np.float32)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ex.compute_blocking(B, policy=pol, win=win, draw=drw)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ex.compute_blocking(B, policy=pol, win=win, draw=drw)
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        dt = nsg.dist.max_over_ranks(dt)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"NN evals/sec at batch={B}", "value": B * args.steps * world / dt, "unit": "evals/s",
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "executor": "random",
+            "config": {"workload": f"CPU REHEARSAL of the multi-rank path, not the benchmark: batch={B}, "
+                                   f"infer::Random stand-in executor on the host, {world} rank(s) over gloo",
+                       "batch_per_gpu": B, "weights_broadcast_bytes": blob_bytes}}))
+    return 0
+
+
+def sample_clock(gpu, out, stop, period=1.0):
+    """rocm-smi sclk / socket power of `gpu` every `period` s until `stop` is set (a child process per sample)."""
+    import re
+    import subprocess
+    while not stop.is_set():
+        try:
+            r = subprocess.run(["/opt/rocm/bin/rocm-smi", "-d", str(gpu), "--showclocks", "--showpower"],
+                               capture_output=True, text=True, timeout=20)
+            m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", r.stdout)
+            w = re.search(r"Power \(W\): ([0-9.]+)", r.stdout)
+            if m:
+                out.append((float(m.group(1)), float(w.group(1)) if w else None))
+        except (OSError, subprocess.SubprocessError):
+            return
+        stop.wait(period)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,14 +399,32 @@ def main():
     ap.add_argument("--selfplay-games-per-group", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--executor", default="hip", choices=["hip", "random"],
+                    help="hip: the MI355X evaluator (the benchmark).  random: CPU rehearsal of the multi-rank path -- "
+                         "gloo backend, the reference's EXECUTOR=random stand-in as the executor, no GPU touched")
     args = ap.parse_args()
+
+    # ---- ranks.  The driver starts N ranks with torch.distributed.run; started WITHOUT a launcher and with
+    # --gpus N > 1 this process becomes the launcher (the reference multiplies executors from one command,
+    # selfplay/main.cc:33,189-195): it touches neither the GPU nor libnsg.so, starts the ranks as a child
+    # process and relays their line.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                  f"run `python bench.py --gpus N` (it starts N ranks itself) or give torch.distributed.run "
+                  f"--nproc-per-node equal to --gpus", file=sys.stderr)
+        sys.exit(2)
+    if args.executor == "random":
+        sys.exit(rehearse_cpu(args, rank, world))
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     # (NSG_BENCH_FORCE_DIST=1: take the multi-rank code path -- RCCL weight broadcast, reductions -- with one rank,
     # to rehearse it on a one-GPU box)
     distributed = world > 1 or os.environ.get("NSG_BENCH_FORCE_DIST") == "1"
@@ -258,6 +435,7 @@ def main():
     nsg = importlib.import_module("nshogi-engine_amd")
     blocks, channels = (int(x) for x in args.net.split("x"))
     B = args.batch
+    ranks_seen = int(round(nsg.dist.sum_over_ranks(1.0, device="cuda"))) if distributed else 1
 
     ev = nsg.Evaluator(local_rank, B, 86, precision=args.precision)
 
@@ -305,13 +483,28 @@ def main():
             ev.forward_resident(B)
         barrier()
         ev.profile_read()
+        import threading
+        clock_samples, clock_stop = [], threading.Event()
+        sampler = None
+        if rank == 0:  # the chip runs this kernel power-limited: the clock it HOLDS under the load is sampled live
+            sampler = threading.Thread(target=sample_clock, args=(local_rank, clock_samples, clock_stop), daemon=True)
+            sampler.start()
         rate, n, secs = held_rate(lambda: ev.forward_resident(B), B, torch.cuda.synchronize, args.sustain_seconds)
+        clock_stop.set()
+        if sampler is not None:
+            sampler.join(timeout=30)
         sprof = ev.profile_read()
         if distributed:
             rate = nsg.dist.sum_over_ranks(rate, device="cuda")
         sustained = {"evals_per_sec": rate, "steps": n, "seconds": secs,
                      "conv_avg_launch_ms": sprof["trunk_ms_total"] / max(sprof["trunk_launches"], 1),
                      "conv_launches_timed": sprof["trunk_launches"]}
+        mhz = [c for c, _ in clock_samples[1:]] or [c for c, _ in clock_samples]  # the first sample may predate the load
+        if mhz:
+            watts = [w for _, w in clock_samples if w is not None]
+            sustained["sclk_mhz_observed"] = sum(mhz) / len(mhz)
+            sustained["sclk_samples"] = len(mhz)
+            sustained["socket_power_w_observed"] = sum(watts) / len(watts) if watts else None
 
     for _ in range(args.warmup):
         ev.forward_resident(B)
@@ -374,6 +567,33 @@ def main():
         barrier()
         ev = None
 
+    # ---- the reference's own metric (bench/batchsize.cc:61-79) on EVERY rank at once: 4 warm-ups, then back-to-back
+    # computeBlocking incl. H2D / D2H on the initial position replicated B times; whole job = sum over ranks
+    ref = None
+    hostev = None
+    if not args.no_host_path:
+        hostev = nsg.Evaluator(local_rank, B, 86, precision=args.precision)
+        hostev.load_memory(blob)
+        pol = np.empty((B, 2187), np.float32)
+        win = np.empty(B, np.float32)
+        drw = np.empty(B, np.float32)
+        secs = max(args.sustain_seconds, 1.0)
+        start = bb if args.positions == "startpos" else nsg.positions.startpos_batch(B)
+        for _ in range(4):
+            hostev.compute_blocking(start, policy=pol, win=win, draw=drw)
+        barrier()
+        rate, n, took = held_rate(lambda: hostev.compute_blocking(start, policy=pol, win=win, draw=drw), B,
+                                  lambda: None, secs)
+        if distributed:
+            rate = nsg.dist.sum_over_ranks(rate, device="cuda")
+        ref = {"definition": "bench/batchsize.cc:61-79: BatchSize * Repeat / wall over back-to-back "
+                             "computeBlocking (H2D + planes + net + D2H + sync), 4 warm-ups, the initial "
+                             "position in every slot" + ("; sum over ranks, all ranks running at once" if world > 1 else ""),
+               "evals_per_sec": rate, "repeat": n, "seconds": took}
+        if world > 1:
+            hostev.close()
+            hostev = None
+
     out = None
     if rank == 0:
         evals = B * args.steps * world
@@ -394,7 +614,7 @@ def main():
                 "distinct": "B distinct positions of random-playout games", "synthetic": "seeded random bitboards"}
         out = {
             "metric": "NN evals/sec at batch=512" if B == 512 else f"NN evals/sec at batch={B}",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "value": value, "unit": "evals/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
@@ -422,6 +642,13 @@ def main():
             "forward_ms_hip_events": prof["forward_ms_total"] / max(prof["forwards"], 1),
             "device": info["device_name"], "compute_units": info["compute_units"],
         }
+        if sustained is not None and sustained.get("sclk_mhz_observed"):
+            # the 2516.6 TF peak assumes the 2.4 GHz boost clock; under a 16-bit MFMA load the chip is power-limited
+            # and holds less -- the same fraction against the clock it actually held
+            pk = peak * sustained["sclk_mhz_observed"] / 2400.0
+            out["roofline"]["peak_at_observed_clock"] = pk
+            out["roofline"]["frac_at_observed_clock"] = achieved / pk
+            out["roofline"]["observed_clock_mhz"] = sustained["sclk_mhz_observed"]
         if sustained is not None:
             out["sustained_evals_per_sec"] = sustained["evals_per_sec"]
             sc = sustained["conv_avg_launch_ms"]
@@ -430,25 +657,12 @@ def main():
             out["sustained"] = sustained
         if sp is not None:
             out["selfplay"] = sp
-        if not args.no_host_path and world == 1:
-            ev = nsg.Evaluator(local_rank, B, 86, precision=args.precision)
-            ev.load_memory(blob)
-            pol = np.empty((B, 2187), np.float32)
-            win = np.empty(B, np.float32)
-            drw = np.empty(B, np.float32)
-            secs = max(args.sustain_seconds, 1.0)
-            # the reference's own definition: 4 warm-ups, then back-to-back computeBlocking incl.
-            # H2D/D2H on the initial position replicated B times (batchsize.cc:47-79)
-            start = bb if args.positions == "startpos" else nsg.positions.startpos_batch(B)
-            for _ in range(4):
-                ev.compute_blocking(start, policy=pol, win=win, draw=drw)
-            rate, n, took = held_rate(lambda: ev.compute_blocking(start, policy=pol, win=win, draw=drw), B,
-                                      lambda: None, secs)
-            ref = {"definition": "bench/batchsize.cc:61-79: BatchSize * Repeat / wall over back-to-back "
-                                 "computeBlocking (H2D + planes + net + D2H + sync), 4 warm-ups, the initial "
-                                 "position in every slot",
-                   "evals_per_sec": rate, "repeat": n, "seconds": took}
-            ref["fraction_of_device_resident"] = rate / (sustained["evals_per_sec"] if sustained else value)
+        if ref is not None:
+            ref["fraction_of_device_resident"] = ref["evals_per_sec"] / (sustained["evals_per_sec"] if sustained else value)
+            out["reference_metric"] = ref
+            out["host_path_evals_per_sec"] = ref["evals_per_sec"]
+        if hostev is not None and world == 1:
+            ev = hostev
             # the B-distinct variant of both rates (real positions of random-playout games)
             other = positions("distinct" if args.positions != "distinct" else "startpos")
             label = "distinct_positions" if args.positions != "distinct" else "startpos"
@@ -458,8 +672,6 @@ def main():
             ev.upload_features(other)
             rate, n, took = held_rate(lambda: ev.forward_resident(B), B, torch.cuda.synchronize, secs)
             out[f"device_resident_evals_per_sec_{label}"] = rate
-            out["reference_metric"] = ref
-            out["host_path_evals_per_sec"] = ref["evals_per_sec"]
             # the same with the legal-move lookup on the device: 80 legal moves per
             # position, softmax priors returned -- D2H shrinks from 8748 B to 320 B per position
             rng = np.random.default_rng(1)
@@ -490,7 +702,7 @@ def main():
             out["other_precisions_evals_per_sec"] = {
                 p: quick_rate(nsg, local_rank, blob, bb, B, p) for p in ("fp32", "f16x3", "f16m8", "f16m6", "fp16", "bf16")
                 if p != args.precision}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:  # rank 0 only; at N > 1 the other ranks idle at the barrier below meanwhile
             out["cpu_baseline"] = cpu_baseline()
             if os.path.exists(SELFPLAY_BIN):
                 out["cpu_baseline"]["selfplay_random_1thread_100playouts"] = selfplay_cpu_baseline()

@@ -771,7 +771,8 @@ static int checkTuningEnv() {
         {"NSG_KSPLIT4_MAX_BATCH", 0, 65535, "largest batch of the four-way K split"},
         {"NSG_ROWSPLIT8_MAX_BATCH", 0, 65535, "largest batch of the four-way K split with two row groups"},
         {"NSG_SPLIT_BATCH", 0, 1, "full part + remainder batches"},
-        {"NSG_SPLIT_BATCH_MAX", 0, 64, "largest batch (quarters of the CU count) that starts with a full chip of two-board tiles"}, {"NSG_ROCTX", 0, 1, "profiler markers"}};
+        {"NSG_SPLIT_BATCH_MAX", 0, 64, "largest batch (quarters of the CU count) that starts with a full chip of two-board tiles"}, {"NSG_ROCTX", 0, 1, "profiler markers"},
+        {"NSG_SHARED_FORCE_COPY", 0, 1, "nsg_load_shared copies even on one device"}};
     for (const Var& v : vars) {
         const char* e = getenv(v.name);
         if (!e) continue;
@@ -1027,7 +1028,10 @@ int nsg_load_shared(nsg_evaluator* ev, nsg_evaluator* src) {
     int rc = bind(ev);
     if (rc) return rc;
     ev->loaded = false;
-    if (ev->gpu == src->gpu) return finishLoad(ev, src->W);
+    // NSG_SHARED_FORCE_COPY=1: take the other-device branch (own allocations + hipMemcpyPeer) for an evaluator of
+    // the SAME device too, so the branch a multi-GPU process runs can be exercised on a one-GPU machine.
+    static const bool forceCopy = [] { const char* e = getenv("NSG_SHARED_FORCE_COPY"); return e && atoi(e) == 1; }();
+    if (ev->gpu == src->gpu && !forceCopy) return finishLoad(ev, src->W);
     const NetWeights& S = *src->W;
     auto W = std::make_shared<NetWeights>();
     W->gpu = ev->gpu; W->prec = S.prec;

@@ -82,6 +82,7 @@ class HashInfer : public infer::Infer {
 int main(int Argc, char* Argv[]) {
     std::string Executor = "hip", Weights, TeacherPath, GameLogPath, LeafLogPath;
     int Gpu = 0, NumGpus = 1, Threads = 2, Precision = NSG_PRECISION_F16X3;
+    std::vector<int> GpuMap;
     double Seconds = 30.0;
     uint64_t MaxGames = 0;
     std::size_t CacheMB = 1024; // selfplay/main.cc:40-41
@@ -98,6 +99,16 @@ int main(int Argc, char* Argv[]) {
         else if (K == "--dfpn-nodes") Opt.DfpnNodes = std::stoull(V);
         else if (K == "--gpu") Gpu = std::stoi(V);
         else if (K == "--num-gpus") NumGpus = std::stoi(V);
+        else if (K == "--gpu-map") { // physical device of every GPU shard, e.g. "0,0": two shards on one device
+            GpuMap.clear();
+            std::size_t P = 0;
+            while (P <= V.size()) {
+                const std::size_t Q = V.find(',', P);
+                GpuMap.push_back(std::stoi(V.substr(P, Q == std::string::npos ? std::string::npos : Q - P)));
+                if (Q == std::string::npos) break;
+                P = Q + 1;
+            }
+        }
         else if (K == "--threads") Threads = std::stoi(V);
         else if (K == "--workers" || K == "--num-search-workers") Opt.Workers = std::stoi(V);
         else if (K == "--solver-threads") Opt.SolverThreads = std::stoi(V);
@@ -116,6 +127,7 @@ int main(int Argc, char* Argv[]) {
         else if (K == "--num-sampling-moves") Opt.NumSamplingMoves = std::stoi(V);
         else { std::cerr << "unknown option " << K << std::endl; return 2; }
     }
+    if (!GpuMap.empty() && (int)GpuMap.size() != NumGpus) { std::cerr << "--gpu-map needs one device per --num-gpus shard" << std::endl; return 2; }
     if (NumGpus < 1 || Threads < 1 || Opt.GamesPerGroup < 1) { std::cerr << "bad --num-gpus/--threads/--games-per-group" << std::endl; return 2; }
     const bool Hip = Executor == "hip";
     const int NumEngines = NumGpus * Threads;
@@ -123,20 +135,24 @@ int main(int Argc, char* Argv[]) {
     // executors: engine e = GPU (e / Threads), thread (e % Threads); two executors per engine
     std::vector<std::unique_ptr<infer::Infer>> Execs;
     infer::Hip* FirstOfAll = nullptr;
+    infer::Hip* FirstOfGpu = nullptr; // first executor of the GPU shard being filled
     for (int E = 0; E < NumEngines; ++E) {
-        const int Device = Gpu + E / Threads;
+        const int Shard = E / Threads;
+        const int Device = GpuMap.empty() ? Gpu + Shard : GpuMap[(std::size_t)Shard];
         for (int G = 0; G < 2; ++G) {
             if (Hip) {
                 auto H = std::make_unique<infer::Hip>(Device, (uint16_t)Opt.GamesPerGroup, (uint16_t)shogi::NumFeaturePlanes);
                 H->setPrecision(Precision);
+                const bool FirstOfShard = E % Threads == 0 && G == 0;
                 if (!FirstOfAll) {
                     H->load(Weights, true); // the one read of the model file
                     FirstOfAll = H.get();
                 } else {
-                    // same GPU: shares the packed weights; first executor of another GPU: peer copy
-                    infer::Hip* FirstOfGpu = static_cast<infer::Hip*>(Execs[(std::size_t)(E / Threads) * Threads * 2].get());
-                    H->loadShared(E % Threads == 0 && G == 0 ? *FirstOfAll : *FirstOfGpu);
+                    // first executor of a further GPU shard: peer copy from the very first executor;
+                    // every other executor shares the packed weights of its own shard's first
+                    H->loadShared(FirstOfShard ? *FirstOfAll : *FirstOfGpu);
                 }
+                if (FirstOfShard) FirstOfGpu = H.get();
                 Execs.push_back(std::move(H));
             } else if (Executor == "zero") {
                 Execs.push_back(std::make_unique<infer::Zero>());

@@ -247,6 +247,32 @@ def test_selfplay_hip_games_do_not_depend_on_grouping(nsg, tmp_path, monkeypatch
 
 
 @pytest.mark.gpu
+def test_selfplay_two_gpu_shards_on_the_one_device(nsg, tmp_path, monkeypatch):
+    """`selfplay --num-gpus 2` (selfplay/main.cc:33,189-195) on the one-GPU box: both shards mapped to device 0
+    (--gpu-map 0,0) and NSG_SHARED_FORCE_COPY=1, so the first executor of shard 1 takes nsg_load_shared's
+    OTHER-device branch (own allocations + hipMemcpyPeer of every packed layer) and the shards' engine threads
+    bind their device themselves.  Same games as the one-shard run: the copied weights are the same weights."""
+    monkeypatch.setenv("NSG_CONV_NB", "1")
+    monkeypatch.setenv("NSG_CONV_NFRAG", "4")
+    path = tmp_path / "net.nsgw"
+    nsg.weights.save(str(path), nsg.weights.make_random(2, 64, seed=3, bn="random"))
+    base = ["--executor", "hip", "--weights", str(path), "--precision", "0", "--playouts", "24", "--seed", "9",
+            "--max-games", "8", "--dfpn-nodes", "2000", "--evaluation-cache-memory-size", "0"]
+    lp0, lp1 = tmp_path / "one.log", tmp_path / "two.log"
+    one = json.loads(run("selfplay", *base, "--threads", "2", "--games-per-group", "3", "--game-log", lp0))
+    monkeypatch.setenv("NSG_SHARED_FORCE_COPY", "1")
+    two = json.loads(run("selfplay", *base, "--num-gpus", "2", "--gpu-map", "0,0", "--threads", "1",
+                         "--games-per-group", "3", "--game-log", lp1))
+    assert one["num_gpus"] == 1 and two["num_gpus"] == 2 and two["concurrent_games"] == one["concurrent_games"] == 12
+    assert len(two["evals_per_sec_by_gpu"]) == 2 and all(x > 0 for x in two["evals_per_sec_by_gpu"])
+    a, b = _game_log(lp0), _game_log(lp1)
+    common = set(a) & set(b)
+    assert len(common) >= 4
+    for gid in common:
+        assert a[gid] == b[gid], gid
+
+
+@pytest.mark.gpu
 def test_selfplay_hip_reproducible(nsg, tmp_path):
     """Self-play on the HIP evaluator: move selection is bit-identical under a fixed seed
     (north_star) from run to run of one configuration (independence from the grouping of the game
