@@ -122,6 +122,26 @@ class OracleNet:
                                        v.ctypes.data, d.ctypes.data)
         return p, v, d
 
+    def evaluate_parallel(self, bb, threads=None):
+        """evaluate() with the boards spread over host threads (the C call releases the GIL and
+        keeps no shared state): what makes a 40-board sample of the 20x256 net a matter of seconds."""
+        import threading
+        bb = np.ascontiguousarray(bb, dtype=np.uint64)
+        b = bb.shape[0]
+        threads = max(1, min(b, threads or min(16, os.cpu_count() or 1)))
+        outs = [None] * b
+
+        def work(t):
+            for i in range(t, b, threads):
+                outs[i] = self.evaluate(bb[i:i + 1])
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return tuple(np.concatenate([o[k] for o in outs]) for k in range(3))
+
 
 def load():
     global _lib

@@ -89,7 +89,7 @@ def test_config3_selfplay_256_games_800_playouts(nsg, tmp_path):
     wpath = tmp_path / "net.nsgw"
     nsg.weights.save(str(wpath), nsg.weights.make_random(20, 256, seed=0, bn="identity"))
     tpath = tmp_path / "games.nsgt"
-    base = ["--executor", "hip", "--weights", wpath, "--precision", 4, "--threads", 1, "--games-per-group", 128,
+    base = ["--executor", "hip", "--weights", wpath, "--precision", 5, "--threads", 1, "--games-per-group", 128,
             "--playouts", 800, "--max-games", 6, "--seed", 21]
     a = run_selfplay(*base, "--teacher", tpath)
     b = run_selfplay(*base)
