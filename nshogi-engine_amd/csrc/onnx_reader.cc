@@ -38,6 +38,8 @@ class Reader {
         const uint64_t Key = varint();
         F->number = (uint32_t)(Key >> 3);
         F->wire = (int)(Key & 7);
+        F->value = 0;
+        F->bytes = Span{}; // a varint field must not leave the previous field's bytes behind
         switch (F->wire) {
         case 0: F->value = varint(); break;
         case 1: F->bytes = take(8); break;
@@ -73,9 +75,16 @@ class Reader {
 std::string str(Span S) { return std::string((const char*)S.p, S.n); }
 
 float f32(Span S) {
+    if (!S.p || S.n < 4) throw Error("malformed protobuf: a float field is not 4 bytes wide");
     float V;
     std::memcpy(&V, S.p, 4);
     return V;
+}
+
+// a field that must be length-delimited (strings, sub-messages, raw_data)
+Span bytesOf(const Field& F, const char* What) {
+    if (F.wire != 2) throw Error(std::string("malformed protobuf: ") + What + " is not length-delimited");
+    return F.bytes;
 }
 
 // ---- ONNX messages (onnx.proto3 field numbers) ----------------------------------------------
@@ -103,14 +112,15 @@ Tensor readTensor(Span S, std::string* Name) {
         case 2: DataType = (int)Fd.value; break;
         case 4: // float_data
             if (Fd.wire == 5) T.F.push_back(f32(Fd.bytes));
-            else for (size_t K = 0; K + 4 <= Fd.bytes.n; K += 4) T.F.push_back(f32(Span{Fd.bytes.p + K, 4}));
+            else if (Fd.wire == 2) for (size_t K = 0; K + 4 <= Fd.bytes.n; K += 4) T.F.push_back(f32(Span{Fd.bytes.p + K, 4}));
+            else throw Error("malformed protobuf: float_data is neither fixed32 nor packed");
             break;
         case 7: // int64_data
             if (Fd.wire == 0) T.I.push_back((int64_t)Fd.value);
             else { Reader P(Fd.bytes); while (!P.done()) T.I.push_back((int64_t)P.varint()); }
             break;
-        case 8: if (Name) *Name = str(Fd.bytes); break;
-        case 9: Raw = Fd.bytes; HasRaw = true; break;
+        case 8: if (Name) *Name = str(bytesOf(Fd, "a tensor name")); break;
+        case 9: Raw = bytesOf(Fd, "raw_data"); HasRaw = true; break;
         case 14: if (Fd.value != 0) throw Error("initializer with external data: not supported (keep the weights inside the .onnx file)"); break;
         default: break;
         }
@@ -169,21 +179,23 @@ Node readNode(Span S) {
     Field Fd;
     while (R.next(&Fd)) {
         switch (Fd.number) {
-        case 1: N.In.push_back(str(Fd.bytes)); break;
-        case 2: N.Out.push_back(str(Fd.bytes)); break;
-        case 3: N.Name = str(Fd.bytes); break;
-        case 4: N.Op = str(Fd.bytes); break;
+        case 1: N.In.push_back(str(bytesOf(Fd, "a node input"))); break;
+        case 2: N.Out.push_back(str(bytesOf(Fd, "a node output"))); break;
+        case 3: N.Name = str(bytesOf(Fd, "a node name")); break;
+        case 4: N.Op = str(bytesOf(Fd, "an op type")); break;
         case 5: {
             std::string Name;
             Attr A;
-            Reader AR(Fd.bytes);
+            Reader AR(bytesOf(Fd, "an attribute"));
             Field Af;
             while (AR.next(&Af)) {
                 switch (Af.number) {
-                case 1: Name = str(Af.bytes); break;
-                case 2: A.F = f32(Af.bytes); A.HasF = true; break;
+                case 1: Name = str(bytesOf(Af, "an attribute name")); break;
+                case 2:
+                    if (Af.wire != 5) throw Error("malformed protobuf: attribute float is not fixed32");
+                    A.F = f32(Af.bytes); A.HasF = true; break;
                 case 3: A.I = (int64_t)Af.value; A.HasI = true; break;
-                case 5: A.T = std::make_shared<Tensor>(readTensor(Af.bytes, nullptr)); break;
+                case 5: A.T = std::make_shared<Tensor>(readTensor(bytesOf(Af, "an attribute tensor"), nullptr)); break;
                 case 8:
                     if (Af.wire == 0) A.Ints.push_back((int64_t)Af.value);
                     else { Reader P(Af.bytes); while (!P.done()) A.Ints.push_back((int64_t)P.varint()); }
@@ -204,7 +216,7 @@ std::string valueInfoName(Span S) {
     Reader R(S);
     Field Fd;
     while (R.next(&Fd))
-        if (Fd.number == 1) return str(Fd.bytes);
+        if (Fd.number == 1) return str(bytesOf(Fd, "a value-info name"));
     return std::string();
 }
 
@@ -260,6 +272,7 @@ struct ConvBn {
     std::vector<float> W;     // [n][cin][k][k]
     std::vector<float> Stats; // [4][n]: gamma, beta, mean, var
     int N = 0, Cin = 0;
+    bool NoBn = false; // identity statistics: var is set to 1 - eps once the model's epsilon is known
     std::string Out;
 };
 
@@ -326,7 +339,9 @@ class Matcher {
             R.Out = B.Out[0];
             return R;
         }
-        // no BN: identity statistics carrying the conv bias (var + eps == 1: folded scale 1)
+        // no BN: identity statistics carrying the conv bias (var + eps == 1: folded scale 1; the
+        // variance is rewritten by finishIdentity() with the epsilon the NSGW header will hold)
+        R.NoBn = true;
         for (int I = 0; I < R.N; ++I) {
             R.Stats[I] = 1.f;
             R.Stats[(size_t)R.N + I] = Bias[I];
@@ -478,7 +493,7 @@ void convert(Span Data, std::vector<unsigned char>* Blob) {
 
     ConvBn Pol = M.convBn(X, PolNode, 1);
     for (int I = 0; I < Pol.N; ++I)
-        if (Pol.Stats[I] != 1.f || std::fabs((double)Pol.Stats[(size_t)3 * Pol.N + I] + Matcher::kEpsDefault - 1.0) > 1e-6)
+        if (!Pol.NoBn)
             fail(PolNode, "the policy conv must be followed directly by the flatten (no BN)");
     {
         const Node& Fl = M.only(Pol.Out, "policy flatten");
@@ -511,6 +526,7 @@ void convert(Span Data, std::vector<unsigned char>* Blob) {
                               (S.Op == "Div" && M.scalarOperand(S, A.Out[0]) == 2.0);
             if (!Half) fail(S, "expected (tanh + 1) * 0.5 or (tanh + 1) / 2");
             Name = S.Out[0];
+            if (Name == "draw") Scale = 2.f; // the device evaluates draw as sigmoid(o): (tanh(z) + 1) / 2 = sigmoid(2 z)
         } else if (Sq.Op == "Sigmoid") {
             Name = Sq.Out[0];
             if (Name == "value") Scale = 0.5f; // sigmoid(z) = (tanh(z / 2) + 1) / 2
@@ -535,6 +551,14 @@ void convert(Span Data, std::vector<unsigned char>* Blob) {
     double Eps = M.EpsSeen.empty() ? Matcher::kEpsDefault : M.EpsSeen[0];
     for (double E : M.EpsSeen)
         if (std::fabs(E - Eps) > 1e-12) throw Error("the BatchNormalization nodes use different epsilons; the NSGW header holds one");
+    // a conv without BN folds with scale 1 only if its variance + THIS model's epsilon is 1
+    auto FinishIdentity = [&](ConvBn* C) {
+        if (!C->NoBn) return;
+        for (int I = 0; I < C->N; ++I) C->Stats[(size_t)3 * C->N + I] = (float)(1.0 - (double)(float)Eps);
+    };
+    FinishIdentity(&Stem);
+    for (ConvBn& B : Blocks) FinishIdentity(&B);
+    FinishIdentity(&Val);
 
     Blob->clear();
     unsigned char Header[64] = {0};

@@ -369,6 +369,7 @@ def import_onnx(data, bn_eps_default=1e-5):
         return c[0]
 
     eps_seen = []
+    identity = []  # statistics of convs without BN
 
     def conv_bn(x, nd, k):
         """Conv [+ BatchNormalization] starting at node nd: returns (weight, bn[4][n], output tensor)."""
@@ -392,7 +393,9 @@ def import_onnx(data, bn_eps_default=1e-5):
             stats = np.stack([g, beta, mu - bias, var])  # a conv bias folds into the BN mean
             return wt.astype(np.float32), stats, b.outputs[0]
         # no BN: identity statistics carrying the conv bias (var + eps == 1 makes the folded scale exactly 1)
+        # (the variance row is rewritten below with the epsilon the model's BatchNormalization nodes use)
         stats = np.stack([np.ones(n), bias, np.zeros(n), np.full(n, 1.0 - bn_eps_default)]).astype(np.float32)
+        identity.append(stats)
         return wt.astype(np.float32), stats, y
 
     def relu(t):
@@ -444,7 +447,7 @@ def import_onnx(data, bn_eps_default=1e-5):
     if len(pol) != 1 or len(val) != 1:
         raise ValueError("cannot tell the policy head from the value head")
     pw, pbn, t = conv_bn(x, pol[0], 1)
-    if not np.array_equal(pbn[0], np.ones_like(pbn[0])) or not np.allclose(pbn[3] + bn_eps_default, 1.0):
+    if not any(pbn is st for st in identity):
         fail(pol[0], "the policy conv must be followed directly by the flatten (no BN)")
     fl = only(t, "policy flatten")
     if fl.op not in ("Flatten", "Reshape") or fl.outputs[0] != "policy":
@@ -499,6 +502,8 @@ def import_onnx(data, bn_eps_default=1e-5):
             if not ((m2.op == "Mul" and scalar(m2, a.outputs[0]) == 0.5) or (m2.op == "Div" and scalar(m2, a.outputs[0]) == 2.0)):
                 fail(m2, "expected (tanh + 1) * 0.5 or (tanh + 1) / 2")
             name = m2.outputs[0]
+            if name == "draw":
+                scale = 2.0  # the device evaluates draw as sigmoid(o): (tanh(z) + 1) / 2 = sigmoid(2 z)
         elif nd2.op == "Sigmoid":
             name = nd2.outputs[0]
             if name == "value":
@@ -518,6 +523,8 @@ def import_onnx(data, bn_eps_default=1e-5):
     eps = eps_seen[0] if eps_seen else bn_eps_default
     if any(abs(e - eps) > 1e-12 for e in eps_seen):
         raise ValueError("the BatchNormalization nodes use different epsilons; the NSGW header holds one")
+    for st in identity:  # a conv without BN folds with scale 1 only if its variance + THIS model's epsilon is 1
+        st[3] = np.float32(1.0 - float(np.float32(eps)))
     w["_meta"] = dict(blocks=k, channels=F, in_channels=w["stem_w"].shape[1], policy_channels=w["policy_w"].shape[0],
                       value_channels=w["value_w"].shape[0], value_hidden=w["fc1_w"].shape[0], bn_eps=eps)
     if w["policy_w"].shape[0] * 81 != 2187:

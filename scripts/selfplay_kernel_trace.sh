@@ -1,5 +1,8 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -euo pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+mkdir -p gpurun_out/r2
 python - <<'PY'
 import importlib, os, sys
 sys.path.insert(0, os.getcwd())

@@ -1,4 +1,4 @@
-"""Generates tests/golden/net_torch_2x64.onnx, net_torch_bn_1x64.onnx and net_torch.npz (run from the repo root:
+"""Generates tests/golden/net_torch_2x64.onnx, net_torch_bn_1x64.onnx, net_torch_sigtanh_eps_1x64.onnx and net_torch.npz (run from the repo root:
 `python tests/golden/make_onnx_golden.py`).
 
 The engine hands its executor an ONNX file (src/infer/trt.cc:109-131, default ./res/model.onnx,
@@ -46,8 +46,9 @@ class Block(nn.Module):
 
 
 class Net(nn.Module):
-    def __init__(self, BLOCKS=BLOCKS):
+    def __init__(self, BLOCKS=BLOCKS, swapped_squashing=False):
         super().__init__()
+        self.swapped_squashing = swapped_squashing
         self.stem = nn.Conv2d(C, F, 3, padding=1, bias=False)
         self.stem_bn = nn.BatchNorm2d(F)
         self.blocks = nn.ModuleList([Block(F) for _ in range(BLOCKS)])
@@ -65,14 +66,18 @@ class Net(nn.Module):
         policy = torch.flatten(self.policy(x), 1)
         v = torch.relu(self.value_bn(self.value_conv(x)))
         h = torch.relu(self.fc1(torch.flatten(v, 1)))
-        value = (torch.tanh(self.fc_value(h)) + 1.0) / 2.0
-        draw = torch.sigmoid(self.fc_draw(h))
+        if self.swapped_squashing:  # sigmoid value head, tanh draw head: the same functions, the other way round
+            value = torch.sigmoid(self.fc_value(h))
+            draw = (torch.tanh(self.fc_draw(h)) + 1.0) * 0.5
+        else:
+            value = (torch.tanh(self.fc_value(h)) + 1.0) / 2.0
+            draw = torch.sigmoid(self.fc_draw(h))
         return policy, value, draw
 
 
-def build(blocks=BLOCKS, seed=20240203):
+def build(blocks=BLOCKS, seed=20240203, swapped_squashing=False, eps=None):
     torch.manual_seed(seed)
-    net = Net(blocks)
+    net = Net(blocks, swapped_squashing)
     g = torch.Generator().manual_seed(7)
     for m in net.modules():
         if isinstance(m, nn.BatchNorm2d):
@@ -81,6 +86,8 @@ def build(blocks=BLOCKS, seed=20240203):
             m.bias.data = torch.randn(n, generator=g) * 0.1
             m.running_mean = torch.randn(n, generator=g) * 0.1
             m.running_var = torch.rand(n, generator=g) + 0.5
+            if eps is not None:
+                m.eps = eps
     return net.eval()
 
 
@@ -110,8 +117,12 @@ def main():
     out = {"bitboards": bb}
     # (a) the usual export: eval mode, constant folding -> BatchNorm folded into conv weight + bias
     # (b) BatchNormalization nodes kept (training=PRESERVE, no folding), one block
-    for name, blocks, fold, seed in (("net_torch_2x64", 2, True, 20240203), ("net_torch_bn_1x64", 1, False, 20240204)):
-        net = build(blocks, seed)
+    # (c) sigmoid value head + tanh draw head, BatchNormalization nodes kept with epsilon 1e-3 (not the default):
+    #     the policy conv (bias, no BN) must still fold with scale exactly 1
+    for name, blocks, fold, seed, swapped, eps in (("net_torch_2x64", 2, True, 20240203, False, None),
+                                                   ("net_torch_bn_1x64", 1, False, 20240204, False, None),
+                                                   ("net_torch_sigtanh_eps_1x64", 1, False, 20240205, True, 1e-3)):
+        net = build(blocks, seed, swapped, eps)
         data = export(net, os.path.join(here, name + ".onnx"), fold)
         with torch.no_grad():
             p, v, d = net.double()(torch.from_numpy(planes).double())

@@ -774,3 +774,27 @@ def test_two_part_batches(nsg, oracle, monkeypatch, mx):
     assert ev.last_plan()["chains"] == 1
     ev.compute_blocking(bb[: cus + cus // 2])
     assert ev.last_plan()["chains"] == 1
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("f16x3", 2e-4), ("f16m6", TOL), ("f16m8", TOL)])
+def test_custom_features_v1_93_planes(nsg, oracle, monkeypatch, precision, tol):
+    """`evaluate::preset::CustomFeaturesV1` (/root/reference/src/evaluate/preset.h:68-122) has 93 planes, not
+    86: the plane count is the evaluator's NumChannels argument (trt.h:44) and the stem's input width, nothing
+    else depends on it.  Both a small-tile and a full-tile batch, outputs and trunk against the oracle; a
+    weight file for another plane count is refused by name."""
+    w = nsg.weights.make_random(2, 256, in_channels=93, seed=93, bn="random")
+    blob = nsg.weights.to_blob(w)
+    net = oracle.net(blob)
+    for batch, full in ((5, False), (6, True)):
+        if full:
+            monkeypatch.setenv("NSG_CONV_NFRAG", "4")
+        ev = nsg.Evaluator(0, 8, 93, precision=precision)
+        ev.load_memory(blob)
+        assert ev.info()["num_channels"] == 93
+        bb = nsg.synth.random_batch(batch, 93, seed=7 + batch, garbage=True)
+        check(ev.compute_blocking(bb), net.evaluate(bb), tol)
+        ev.close()
+    ev = nsg.Evaluator(0, 8, 86, precision=precision)
+    with pytest.raises(nsg.NsgError, match="93 input planes"):
+        ev.load_memory(blob)
+    ev.close()

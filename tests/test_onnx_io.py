@@ -76,7 +76,10 @@ def test_refuses_foreign_structures():
 
 # ---- models serialised by PyTorch's own exporter (tests/golden/make_onnx_golden.py) ----------
 
-TORCH_MODELS = [("net_torch_2x64", 2, False), ("net_torch_bn_1x64", 1, True)]
+# the third: sigmoid VALUE head, tanh DRAW head ((tanh + 1) * 0.5 = sigmoid(2 z): the draw row must be doubled,
+# like the value row is halved for a sigmoid value head), BatchNormalization epsilon 1e-3 (not the default:
+# the BN-less policy conv must still fold with scale 1)
+TORCH_MODELS = [("net_torch_2x64", 2, False), ("net_torch_bn_1x64", 1, True), ("net_torch_sigtanh_eps_1x64", 1, True)]
 
 
 @pytest.mark.parametrize("name,blocks,has_bn", TORCH_MODELS)
@@ -108,6 +111,44 @@ def test_cpp_reader_equals_python_importer_on_this_builds_writer(fold, sig):
     w = nsg.weights.make_random(2, 64, seed=17, bn="random")
     data = oio.export_onnx(w, fold_bn=fold, value_sigmoid=sig)
     assert nsg.convert_onnx(data) == nsg.weights.to_blob(oio.import_onnx(data))
+
+
+def test_nondefault_epsilon_reaches_the_header_and_the_identity_statistics(golden_dir):
+    w = oio.import_onnx(open(f"{golden_dir}/net_torch_sigtanh_eps_1x64.onnx", "rb").read())
+    assert abs(w["_meta"]["bn_eps"] - 1e-3) < 1e-9
+
+
+def test_malformed_protobuf_fields_are_format_errors_not_crashes(golden_dir):
+    """Wire types are validated before a field's bytes are used: a float attribute sent as a
+    varint, a name sent as a varint, a short float field -- NSG_E_FORMAT with a message, never a crash."""
+    def msg(fields):
+        return b"".join(fields)
+
+    def ld(num, payload):  # length-delimited field
+        assert len(payload) < 128
+        return bytes([(num << 3) | 2, len(payload)]) + payload
+
+    def vi(num, v):
+        return bytes([(num << 3) | 0, v])
+
+    # NodeProto with an attribute whose float field (2) arrives as a varint
+    bad_attr = ld(5, msg([ld(1, b"epsilon"), vi(2, 7)]))
+    node = msg([ld(1, b"x"), ld(2, b"y"), ld(4, b"Relu"), bad_attr])
+    model = ld(7, msg([ld(1, node)]))
+    with pytest.raises(nsg.NsgError, match="fixed32"):
+        nsg.convert_onnx(model)
+    # a node name (3) sent as a varint
+    model = ld(7, msg([ld(1, msg([vi(3, 1), ld(4, b"Relu")]))]))
+    with pytest.raises(nsg.NsgError, match="length-delimited"):
+        nsg.convert_onnx(model)
+    # TensorProto whose float_data (4) is a varint
+    tensor = msg([vi(1, 1), vi(2, 1), vi(4, 3)])
+    with pytest.raises(nsg.NsgError, match="float_data"):
+        nsg.convert_onnx(ld(7, msg([ld(5, tensor)])))
+    # raw_data (9) as fixed64 instead of bytes
+    tensor = msg([vi(1, 2), vi(2, 1), bytes([(9 << 3) | 1]) + b"\0" * 8])
+    with pytest.raises(nsg.NsgError, match="length-delimited"):
+        nsg.convert_onnx(ld(7, msg([ld(5, tensor)])))
 
 
 def test_cpp_reader_refuses_with_a_message(golden_dir):
