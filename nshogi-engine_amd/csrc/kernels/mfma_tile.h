@@ -73,7 +73,11 @@ template <int MODE, int SIZE, int NWAVES, int NBUF = 2>
 struct Geom {
     static constexpr bool kBoards = (MODE == kConv);
     static constexpr int kRows = kBoards ? SIZE * 81 : SIZE * 16;
+#ifdef NSG_EXP_DROP_TAIL_FRAGMENT // timing-only (wrong results): a two-board tile without its 11th, 2-row fragment
+    static constexpr int kMF = (kBoards && SIZE == 2) ? 10 : (kRows + 15) / 16;
+#else
     static constexpr int kMF = (kRows + 15) / 16;
+#endif
     static constexpr int kEntries = kBoards ? SIZE * 110 + 24 : kMF * 16;
     static constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
     static constexpr int kBuf = 8 * kPlane;  // one 128-byte channel chunk
@@ -229,6 +233,7 @@ struct Args {
     int kSplits;              // kDense: K is split over gridDim.z = kSplits workgroups, each writing its raw
     size_t partStride;        //   partial sums (no bias, no ReLU) at y + z*partStride floats
     unsigned long long* stamps; // diagnostic builds only (NSG_DIAG_STAMPS): 8 u64 per workgroup
+    int exp = 0;                // experiment builds only (NSG_EXP_RUNTIME): timing-only switches
 };
 
 // What tileKernel takes behind its preloaded scalar arguments.
@@ -946,6 +951,19 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         return;
     }
 
+#ifdef NSG_EXP_RUNTIME // timing-only (wrong results), switched at run time so that the activations the
+    // kernels read stay those of the last correct forward: bit 1 = skip the whole epilogue
+    if constexpr (MODE == kConv && NFRAG == 4 && isMx(PREC)) {
+        if (A.exp & 2) {
+#pragma unroll
+            for (int f = 0; f < kMFw; ++f)
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) asm volatile("" ::"v"(acc[f][j]));
+            NSG_STAMP(3);
+            return;
+        }
+    }
+#endif
     if constexpr (MODE == kConv && NFRAG == 4) {
         // (K split: after the exchange a wave owns kMFe of the row fragments, from fBaseE on)
         constexpr int kMFe = (kMFw + KS - 1) / KS;
@@ -1252,7 +1270,12 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
                     const int m = (fBaseE + f) * 16 + it * kRPI + lrow;
+#ifdef NSG_EXP_RUNTIME // bit 0 = the staged rows are kept alive, not stored
+                    asm volatile("" ::"v"(tt[it]));
+                    if (__builtin_expect(m < rowLimit && !(A.exp & 1), 1))
+#else
                     if (__builtin_expect(m < rowLimit, 1))
+#endif
                         *reinterpret_cast<u32x4*>(yBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff) = tt[it];
                 }
             }
@@ -1323,7 +1346,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, N
     int kdim, int cout, int flags /* bit 0: relu, bit 1: outF16x3 */, float accScale, const ArgsTail T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Args A{x, w, bias, res, y, T.policy, T.vfeat, kdim, cout, T.totalRows, flags & 1, T.valueChannels,
-                 T.vfeatStride, accScale, (flags >> 1) & 1, T.kSplits, T.partStride, T.stamps};
+                 T.vfeatStride, accScale, (flags >> 1) & 1, T.kSplits, T.partStride, T.stamps, flags >> 2};
     tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS>(A, smem, true);
 }
 
@@ -1355,6 +1378,12 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
     }
 }
 
+#ifdef NSG_EXP_RUNTIME
+inline int expFlags() { const char* e = getenv("NSG_EXP_FLAGS"); return e ? atoi(e) << 2 : 0; }
+#else
+constexpr int expFlags() { return 0; }
+#endif
+
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int MS = 1, int KS = 1>
 hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
     using G = Geom<MODE, SIZE, NWAVES, (isMx(PREC) ? (KS > 1 ? 8 : 4) : 2)>;
@@ -1378,7 +1407,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
             attrDevMask.fetch_or(1 << dev);
         }
         hipLaunchKernelGGL(k, dim3(gridX, gy, kRowWG ? MS : 1), dim3(G::kThreads), G::kLdsAlloc, stream, a.x, a.w, a.res, a.y, a.bias,
-                           a.kdim, a.cout, (a.relu ? 1 : 0) | (a.outF16x3 ? 2 : 0), a.accScale, tailOf(a));
+                           a.kdim, a.cout, (a.relu ? 1 : 0) | (a.outF16x3 ? 2 : 0) | expFlags(), a.accScale, tailOf(a));
     } else {
         auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false, MS, KS>;
         static std::atomic<int> attrDevMask{0};
@@ -1390,7 +1419,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
             attrDevMask.fetch_or(1 << dev);
         }
         hipLaunchKernelGGL(k, dim3(gridX, gy, MODE == kDense ? a.kSplits : (kRowWG ? MS : 1)), dim3(G::kThreads), G::kLdsAlloc, stream,
-                           a.x, a.w, a.res, a.y, a.bias, a.kdim, a.cout, (a.relu ? 1 : 0) | (a.outF16x3 ? 2 : 0), a.accScale, tailOf(a));
+                           a.x, a.w, a.res, a.y, a.bias, a.kdim, a.cout, (a.relu ? 1 : 0) | (a.outF16x3 ? 2 : 0) | expFlags(), a.accScale, tailOf(a));
     }
     return hipGetLastError();
 }
