@@ -86,7 +86,9 @@ struct Geom {
     // whole register file), so it takes the whole 160 KiB and moves 9 of its 11 fragments per batch --
     // the residual loads of a batch are one global round trip, and batches run back to back.
     static constexpr int kEpi = kLds; // (the whole 160 KiB = 9 fragments per batch was 3 % slower: fewer, longer batches overlap less)
-    static constexpr int kLdsAlloc = (kEpi > kLds ? kEpi : kLds) + 1024; // + one trash slot per lane for masked staging lanes
+    // + one trash slot per lane for masked staging lanes (1 KiB) + the row table of the edge-packed tiles (1 KiB)
+    static constexpr int kRowTabOff = (kEpi > kLds ? kEpi : kLds) + 1024;
+    static constexpr int kLdsAlloc = kRowTabOff + 1024;
     static constexpr int kThreads = NWAVES * 64;
     static constexpr int kItems = (2 * kMF + NWAVES - 1) / NWAVES;
     static constexpr int kTaps = kBoards ? 9 : 1;
@@ -301,6 +303,86 @@ struct M8Seq {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
+// Row order of a TWO-BOARD MX tile ("edge-packed rows").  A 3x3 "same" convolution multiplies 14 % of its
+// (row, tap) pairs by the zero halo: every square of the top row has no dy = -1 neighbours, and so on.  In
+// natural row order every 16-row fragment mixes edge and interior squares and needs all nine taps; here
+// the 64 edge squares of the two boards form four fragments that each lack one whole line of taps, and the
+// MFMAs (and LDS fragment reads) of those (fragment, tap) pairs are simply not issued -- adding w * 0 is
+// an exact no-op, so the outputs are bit-identical to the full loop's.  Fragments:
+//   0..5  interior squares (y, x in 1..7), 96 of the 98        all nine taps
+//   6     top rows, x = 1..8 of both boards                    no dy = -1 taps
+//   7     bottom rows, x = 0..7                                no dy = +1 taps
+//   8     left columns y = 1..7 + the corners (0,0)            no dx = -1 taps
+//   9     right columns y = 1..7 + the corners (8,8)           no dx = +1 taps
+//   10    the last 2 interior squares (+ 14 padding rows)      all nine taps
+// 99 -> 87 (fragment, tap) pairs per chunk: 12 % fewer matrix instructions and fragment reads.
+struct EdgeRows {
+    static constexpr int kMF = 11;
+    static constexpr bool needTap(int f, int t) {
+        return f == 6 ? t / 3 != 0 : f == 7 ? t / 3 != 2 : f == 8 ? t % 3 != 0 : f == 9 ? t % 3 != 2 : true;
+    }
+    // board, rank and file of row r of fragment f; false = padding row
+    static constexpr __host__ __device__ bool square(int f, int r, int& b, int& y, int& x) {
+        b = r >> 3;
+        const int k = r & 7;
+        if (f < 6 || f == 10) {
+            if (f == 10 && r >= 2) return false;
+            const int i = (f < 6 ? f * 16 : 96) + r;
+            b = i >= 49 ? 1 : 0;
+            const int j = i - b * 49;
+            const int q = (j * 37) >> 8; // j / 7 for j < 49
+            y = 1 + q;
+            x = 1 + j - q * 7;
+        } else if (f == 6) {
+            y = 0; x = 1 + k;
+        } else if (f == 7) {
+            y = 8; x = k;
+        } else if (f == 8) {
+            y = k < 7 ? 1 + k : 0; x = 0;
+        } else {
+            y = k < 7 ? 1 + k : 8; x = 8;
+        }
+        return true;
+    }
+    // natural row index b*81 + y*9 + x of row r of fragment f; -1 = padding row
+    static constexpr __host__ __device__ int rowOf(int f, int r) {
+        int b = 0, y = 0, x = 0;
+        return square(f, r, b, y, x) ? b * 81 + y * 9 + x : -1;
+    }
+};
+
+// The (slab, fragment) steps of one chunk pair in issue order, and their inverse: with edge-packed rows
+// the steps whose tap a fragment does not need are left out.
+template <int SLABS, int MF, bool PERM>
+struct StepSeq {
+    struct Tab {
+        int n;
+        short slab[SLABS * MF], frag[SLABS * MF], index[SLABS * MF];
+    };
+    static constexpr bool active(int s, int f) { return !PERM || EdgeRows::needTap(f, s / 3); }
+    static constexpr Tab make() {
+        Tab t{};
+        int n = 0;
+        for (int s = 0; s < SLABS; ++s)
+            for (int f = 0; f < MF; ++f) {
+                t.index[s * MF + f] = (short)(active(s, f) ? n : -1);
+                if (active(s, f)) {
+                    t.slab[n] = (short)s;
+                    t.frag[n] = (short)f;
+                    ++n;
+                }
+            }
+        for (int q = n; q < SLABS * MF; ++q) t.slab[q] = t.frag[q] = 0;
+        t.n = n;
+        return t;
+    }
+    static constexpr Tab kTab = make();
+    static constexpr int kSteps = kTab.n;
+    static constexpr int slab(int q) { return kTab.slab[q]; }
+    static constexpr int frag(int q) { return kTab.frag[q]; }
+    static constexpr int index(int s, int f) { return kTab.index[s * MF + f]; }
+};
+
 // One layer's work for this workgroup.  RES: 0 = no residual, 1 = residual,
 // 2 = decided at run time by A.res (persistent trunk kernel).
 // MS (row split, small one-board tiles): the waves of a workgroup form MS groups, each computing
@@ -335,6 +417,13 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                               (NFRAG < 4 || isMx(PREC))),
                   "row split: one-board conv tiles (small tiles, or kF16m8 full-channel tiles)");
     constexpr int kMFw = G::kMF / MS; // row fragments this wave computes
+    // edge-packed row order (EdgeRows): the two-board MX tiles
+#ifdef NSG_NO_EDGE_ROWS // A/B partner build (make ab ABFLAGS=-DNSG_NO_EDGE_ROWS): natural row order, all taps
+    constexpr bool kPerm = false;
+#else
+    constexpr bool kPerm = isMx(PREC) && MODE == kConv && SIZE == 2 && MS == 1 && KS == 1;
+#endif
+    static_assert(!kPerm || kMFw == EdgeRows::kMF, "edge-packed rows: eleven fragments");
 
     int tidOpaque = threadIdx.x;
     // (opaque to the optimiser: inside the persistent trunk kernel the per-lane address tables
@@ -409,16 +498,33 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 
     // per-lane LDS read bases of the row fragments
     int abase[kMFw];
-#pragma unroll
-    for (int f = 0; f < kMFw; ++f) {
-        const int m = (fBase + f) * 16 + li;
-        if constexpr (G::kBoards) {
-            const int p = (m < G::kRows) ? entryOfRow<true>(m) : 11; // 11: every tap reads zeros
-            abase[f] = g * G::kPlane + (p - 11) * 16;
-        } else {
-            abase[f] = g * G::kPlane + m * 16;
-        }
+    // (edge-packed rows: eleven (fragment, lane) -> square decodes and the epilogue's row table, ~300 instructions.
+    // They run AFTER the first weight and tile requests have been issued, not in front of them; the table:
+    // the epilogue moves a fragment's 16 rows to and from global memory, and they are no longer consecutive
+    // there -- byte offset of row r = it*4 + lrow of fragment f inside the tile at [(f*4 + lrow)*4 + it],
+    // ~0 = padding row, written by the sixteen lanes that have just computed the natural row of (f, li))
+#define NSG_COMPUTE_ABASE \
+_Pragma("unroll") \
+    for (int f = 0; f < kMFw; ++f) { \
+        [[maybe_unused]] int eb = 0, ey = 0, ex = 0; \
+        [[maybe_unused]] bool eok = true; \
+        if constexpr (kPerm) eok = EdgeRows::square(f, li, eb, ey, ex); \
+        const int m = kPerm ? (eok ? eb * 81 + ey * 9 + ex : -1) : (fBase + f) * 16 + li; \
+        if constexpr (kPerm) { \
+            static_assert(NFRAG * 16 * ES == 256, "edge-packed rows: 256-byte row slices (4 rows per instruction)"); \
+            if (wave == 0 && g == 0) \
+                reinterpret_cast<unsigned*>(smem + G::kRowTabOff)[(f * 4 + (li & 3)) * 4 + (li >> 2)] = \
+                    m >= 0 ? (unsigned)m * (unsigned)(A.cout * ES) : ~0u; \
+        } \
+        if constexpr (G::kBoards) { \
+            const int p = kPerm ? (eok ? 24 + eb * 110 + (ey + 1) * 10 + ex : 11) \
+                                : ((m < G::kRows) ? entryOfRow<true>(m) : 11); \
+            abase[f] = g * G::kPlane + (p - 11) * 16; \
+        } else { \
+            abase[f] = g * G::kPlane + m * 16; \
+        } \
     }
+    if constexpr (!kPerm) { NSG_COMPUTE_ABASE }
 
     // Pins every accumulator to an AGPR at the top of a K-chunk iteration.  Without it the
     // register allocator gives the loop-carried accumulators different registers at the
@@ -456,7 +562,8 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // computed and the pair being staged.
         using Q = M8Seq<G::kTaps>;
         static_assert((2 * G::kTaps) % 3 == 0, "three f16 weight sets must carry across chunk pairs");
-        constexpr int kSteps = Q::kSlabs * kMFw;
+        using ST = StepSeq<Q::kSlabs, kMFw, kPerm>;
+        constexpr int kSteps = ST::kSteps; // Q::kSlabs * kMFw, less the (fragment, tap) pairs edge-packed rows leave out
         constexpr int kWin = 9, kD = 7;
         static_assert(kSteps % kWin == 0, "window slot must carry across chunk pairs");
         // Next pair's tiles.  All workgroups run in lock-step, so tile loads issued at one point
@@ -467,7 +574,8 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // top of slab 25; one barrier per pair, just before the first next-pair fragment request.
         constexpr int kLoadSlabs = G::kItems < 6 ? G::kItems : 6, kLoadSlabA = 2, kLoadSlabB = 13;
         constexpr int kBarStep = kSteps - kD;
-        constexpr int kWriteStepA = 12 * kMFw, kWriteStepB = 25 * kMFw < kBarStep ? 25 * kMFw : kBarStep - 1;
+        constexpr int kWriteStepA = ST::index(12, 0), kWriteStepB = ST::index(25, 0) < kBarStep ? ST::index(25, 0) : kBarStep - 1;
+        static_assert(ST::index(12, 0) >= 0 && ST::index(25, 0) >= 0, "fragment 0 runs every tap");
         static_assert(kWriteStepB < kBarStep, "tile staging order");
         auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
         // MX operand of lane (li, g): 32 fp8 bytes of chunk g>>1 (A / B buffer); g&1 ? lo bytes : hi bytes
@@ -494,6 +602,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
         for (int k = 0; k < G::kItems; ++k) st1[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + 128);
         NSG_STAMP(4);
+        if constexpr (kPerm) { NSG_COMPUTE_ABASE }
         if (zeroLds) zeroHalo<G>(smem, tid);
         __syncthreads(); // zero fill done before staging writes
         NSG_STAMP(5);
@@ -523,7 +632,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         {                                                                                         \
             const int q_ = (QQ) % kSteps;                                                         \
             const unsigned char* b_ = ((QQ) >= kSteps) ? (NXT) : (CUR);                           \
-            const int s_ = q_ / kMFw, f_ = q_ % kMFw;                                         \
+            const int s_ = ST::slab(q_), f_ = ST::frag(q_);                                       \
             if (Q::isX(s_)) {                                                                     \
                 const unsigned char* ap_ = b_ + abase[f_] + offp8 + tapOff(Q::tap(s_));           \
                 aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(ap_);                        \
@@ -548,7 +657,8 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             for (int s = 0; s < Q::kSlabs; ++s) {
 #pragma unroll
                 for (int f = 0; f < kMFw; ++f) {
-                    const int q = s * kMFw + f;
+                    if (!ST::active(s, f)) continue; // (edge-packed rows: this fragment has no neighbours under this tap)
+                    const int q = ST::index(s, f);
 #ifdef NSG_DIAG_SLABS
                     // slab timeline of workgroup 0 / wave 0, stored behind the per-workgroup stamps
                     // (its s_memtime drains the fragment window: a separate diagnostic build)
@@ -608,7 +718,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
                     // issue order inside the step: the first MFMA, then the requests (they issue in its
                     // shadow instead of between two steps), then the other MFMAs
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (Q::isX(((q + kD) % kSteps) / kMFw)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (Q::isX(ST::slab((q + kD) % kSteps))) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     if (f == 0 && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, NFRAG, 0);
                     if (f == 0 && reqX) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NFRAG, 0);
@@ -856,6 +966,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     }
 
 #undef NSG_STAGE_LOAD
+#undef NSG_COMPUTE_ABASE
 #undef NSG_PIN_ACC_AGPR
 #undef NSG_STAGE_WRITE
     NSG_STAMP(2);
@@ -1009,8 +1120,22 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         const size_t tileOff = (row0 + (size_t)fBaseE * 16) * rowBytes + sliceOff;
         const unsigned char* resBase = A.res + tileOff;
         unsigned char* yBase = A.y + tileOff;
+        // edge-packed rows: per-lane offsets of the four rows (it = 0..3) this lane moves for fragment f
+        [[maybe_unused]] const unsigned permLane = (unsigned)lpc * 16u;
+        auto rowOffs = [&](int f) -> u32x4 {
+            if constexpr (kPerm) return *reinterpret_cast<const u32x4*>(smem + G::kRowTabOff + (f * 4 + lrow) * 16);
+            else return u32x4{0u, 0u, 0u, 0u};
+        };
+        // (ok, byte offset from resBase / yBase) of row it*kRPI + lrow of fragment f
+        auto rowOk = [&](int f, int it, const u32x4& ro) -> bool {
+            if constexpr (kPerm) return f != EdgeRows::kMF - 1 || ro[it] != ~0u; // only the last fragment has padding rows
+            else return (fBaseE + f) * 16 + it * kRPI + lrow < rowLimit;
+        };
+        auto rowByte = [&](int f, int it, const u32x4& ro) -> size_t {
+            if constexpr (kPerm) return (size_t)(ro[it] + permLane);
+            else return (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff;
+        };
 
-#define NSG_RES_FRAG(F) (F)
         // Most of this wave's residual slice is requested up front (the main loop's operand registers
         // are dead), so the fragment pipeline below does not wait a global round trip per fragment.
         // (only the first kPreFrags fragments: with all eleven the epilogue spills; kernels capped at
@@ -1020,14 +1145,15 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         u32x4 rpre[kPreFrags ? kPreFrags : 1][kIPF];
         if constexpr (kPreFrags > 0) {
 #pragma unroll
-            for (int f = 0; f < kPreFrags; ++f)
+            for (int f = 0; f < kPreFrags; ++f) {
+                const u32x4 ro = rowOffs(f);
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
-                    const int m = (fBaseE + f) * 16 + it * kRPI + lrow;
                     rpre[f][it] = u32x4{0u, 0u, 0u, 0u};
-                    if (__builtin_expect(m < rowLimit, 1))
-                        rpre[f][it] = *reinterpret_cast<const u32x4*>(resBase + (size_t)(NSG_RES_FRAG(f) * 16 + it * kRPI) * rowBytes + laneOff);
+                    if (__builtin_expect(rowOk(f, it, ro), 1))
+                        rpre[f][it] = *reinterpret_cast<const u32x4*>(resBase + rowByte(f, it, ro));
                 }
+            }
         }
 
         // Three stages per fragment, software-pipelined over the fragments so that no stage waits for
@@ -1043,24 +1169,29 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         u32x4 tt[kIPF];
 #pragma unroll
         for (int i = -1; i <= kMFe; ++i) {
+            // (edge-packed rows: the row offsets of both stages are read from the table up front, so that
+            // their LDS round trip overlaps the stages' own instead of stalling each in turn)
+            [[maybe_unused]] u32x4 roS = u32x4{0u, 0u, 0u, 0u}, roR = u32x4{0u, 0u, 0u, 0u};
             if (i >= 1) { // ---- S(i-1), reads
                 const int f = i - 1;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it)
                     tt[it] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + (it * kRPI + lrow) * kRowS + lpc * 16);
+                roS = rowOffs(f);
             }
             if (hasRes && i + 1 < kMFe) { // ---- R(i+1)
                 const int f = i + 1;
+                if (f >= kPreFrags) roR = rowOffs(f);
+                const u32x4 ro = roR;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
                     const int r = it * kRPI + lrow;
-                    const int m = (fBaseE + f) * 16 + r;
                     u32x4 t = u32x4{0u, 0u, 0u, 0u};
                     if (f < kPreFrags) {
                         t = rpre[f < kPreFrags ? f : 0][it];
                     } else {
-                        if (__builtin_expect(m < rowLimit, 1))
-                            t = *reinterpret_cast<const u32x4*>(resBase + (size_t)(NSG_RES_FRAG(f) * 16 + it * kRPI) * rowBytes + laneOff);
+                        if (__builtin_expect(rowOk(f, it, ro), 1))
+                            t = *reinterpret_cast<const u32x4*>(resBase + rowByte(f, it, ro));
                     }
                     *reinterpret_cast<u32x4*>(ebuf + (f % kRegions) * kFragBytes + r * kRowS + lpc * 16) = t;
                 }
@@ -1267,16 +1398,16 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
             }
             if (i >= 1) { // ---- S(i-1), stores: kRPI rows x kRowB contiguous bytes per instruction
                 const int f = i - 1;
+                const u32x4 ro = roS;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
-                    const int m = (fBaseE + f) * 16 + it * kRPI + lrow;
 #ifdef NSG_EXP_RUNTIME // bit 0 = the staged rows are kept alive, not stored
                     asm volatile("" ::"v"(tt[it]));
-                    if (__builtin_expect(m < rowLimit && !(A.exp & 1), 1))
+                    if (__builtin_expect(rowOk(f, it, ro) && !(A.exp & 1), 1))
 #else
-                    if (__builtin_expect(m < rowLimit, 1))
+                    if (__builtin_expect(rowOk(f, it, ro), 1))
 #endif
-                        *reinterpret_cast<u32x4*>(yBase + (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff) = tt[it];
+                        *reinterpret_cast<u32x4*>(yBase + rowByte(f, it, ro)) = tt[it];
                 }
             }
         }

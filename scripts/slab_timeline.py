@@ -5,7 +5,7 @@ import ctypes, importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["NSG_LIB"] = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "libnsg_diag.so")
+os.environ["NSG_LIB"] = os.environ.get("NSG_DIAG_LIB") or os.path.join(ROOT, "nshogi-engine_amd", "csrc", "libnsg_diag.so")
 nsg = importlib.import_module("nshogi-engine_amd")
 blocks, ch, B = 20, 256, 512
 ev = nsg.Evaluator(0, B, 86, precision=(sys.argv[1] if len(sys.argv) > 1 else "f16m8"))

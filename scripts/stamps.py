@@ -5,7 +5,7 @@ import argparse, ctypes, importlib, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["NSG_LIB"] = os.path.join(ROOT, "nshogi-engine_amd", "csrc", "libnsg_diag.so")
+os.environ["NSG_LIB"] = os.environ.get("NSG_DIAG_LIB") or os.path.join(ROOT, "nshogi-engine_amd", "csrc", "libnsg_diag.so")
 ap = argparse.ArgumentParser(); ap.add_argument("--precision", default="f16x3"); ap.add_argument("--net", default="20x256")
 ap.add_argument("--batch", type=int, default=512); a = ap.parse_args()
 nsg = importlib.import_module("nshogi-engine_amd")
