@@ -272,6 +272,9 @@ int nsg_get_last_plan(nsg_evaluator* ev, int* boards_per_group, int* fragments_p
  * with k_split = 4 a row_split of 2, 3 or 6 means that many WORKGROUPS per channel group, each on its
  * share of the rows (the smallest batches).  1 / 1 for ordinary tiles, 0 / 0 before the first pass. */
 int nsg_get_last_split(nsg_evaluator* ev, int* row_split, int* k_split);
+/* ... and how many waves of a channel group shared every chunk pair's SLABS between them (two-board MX tiles at
+ * mid batches: 4 up to CUs/2 boards, 2 up to CUs boards); 1 for every other plan, 0 before the first pass. */
+int nsg_get_last_slab_split(nsg_evaluator* ev, int* slab_split);
 /* Arithmetic the most recent forward pass ran its trunk in (NSG_PRECISION_*; -1 before
  * the first pass).  An F16M8 evaluator runs small batches for which it has no F16M8 tile plan
  * (channel counts other than 256) as F16X3. */

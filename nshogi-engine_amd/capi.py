@@ -104,6 +104,7 @@ def load_library():
     lib.nsg_get_last_plan.argtypes = [vp, ip, ip, ip, ip]
     lib.nsg_get_last_trunk_precision.argtypes = [vp, ip]
     lib.nsg_get_last_split.argtypes = [vp, ip, ip]
+    lib.nsg_get_last_slab_split.argtypes = [vp, ip]
     lib.nsg_compute_gather_blocking.argtypes = [vp, vp, sz, vp, vp, i, vp, vp, vp]
     lib.nsg_compute_gather_nonblocking.argtypes = [vp, vp, sz, vp, vp, i, vp, vp, vp]
     lib.nsg_cpu_executor_create.argtypes = [i, ctypes.c_uint64, ctypes.POINTER(vp)]
@@ -311,6 +312,9 @@ class Evaluator:
         rs, ks = ctypes.c_int(), ctypes.c_int()
         _check(self._lib.nsg_get_last_split(self._h, ctypes.byref(rs), ctypes.byref(ks)))
         d["row_split"], d["k_split"] = rs.value, ks.value
+        ss = ctypes.c_int()
+        _check(self._lib.nsg_get_last_slab_split(self._h, ctypes.byref(ss)))
+        d["slab_split"] = ss.value
         tp = ctypes.c_int()
         _check(self._lib.nsg_get_last_trunk_precision(self._h, ctypes.byref(tp)))
         d["trunk_precision"] = {v: k for k, v in _PREC_NAMES.items() if k not in ("f32", "f16")}.get(tp.value, tp.value)

@@ -82,6 +82,7 @@ struct ConvPlan {
     int nwaves;  // waves per workgroup
     int msplit = 1; // wave groups that split the tile's row fragments between them (small one-board tiles: 2)
     int ksplit = 1; // kF16m8 one-board tiles: waves of a channel group that split the input-channel chunk pairs between them
+    int sslab = 1;  // MX two-board tiles at mid batches: waves of a channel group that split every chunk pair's slabs between them
 };
 constexpr int kNfrag = 4; // every packed tensor uses 4 fragments (64 channels) per wave
 
@@ -92,6 +93,7 @@ struct ConvTuning {
     int splitBatch = 1;    // NSG_SPLIT_BATCH=0: never run a batch as a full part + remainder
     int splitBatchMax3 = 9;  // NSG_SPLIT_BATCH_MAX: largest batch, in quarters of the CU count, that starts with a full chip of two-board tiles
     int rowsplit8Max = -1; // NSG_ROWSPLIT8_MAX_BATCH: largest batch whose four-way K split also splits the rows over two workgroups (-1: CUs / 8)
+    int slabSplit = 0;     // NSG_SLAB_SPLIT=1: slab-split two-board tiles at mid batches (measured 8-11 % slower than the plans they would replace: opt-in)
     bool fullTilesOnly = false; // kF16m8: 4 fragments per wave at every batch size
 };
 ConvTuning readConvTuning();

@@ -351,36 +351,105 @@ struct EdgeRows {
     }
 };
 
-// The (slab, fragment) steps of one chunk pair in issue order, and their inverse: with edge-packed rows
-// the steps whose tap a fragment does not need are left out.
-template <int SLABS, int MF, bool PERM>
-struct StepSeq {
+// "Slab split" (SS waves per 64-channel group, two-board MX tiles at mid batches): the SS waves of a channel
+// group share the K range of every chunk pair by SLABS -- each runs its own static subset of the pair's 27
+// slabs (18 f16 main slabs M0..M17 = (tap, chunk A|B), 9 MX slabs X0..X8) for ALL row fragments and the
+// group adds its accumulators up at the end.  A two-board tile of 64 channels is then one workgroup:
+// at 128 boards 256 workgroups, each streaming a quarter of the layer's weights through its L1 for TWO
+// boards (the one-board tiles stream half of them for one), with the two-board tile's edge-packed rows.
+// The subsets are balanced in (slab, fragment) steps with edge-packed rows (66 / 67 / 62 / 66 of 261 for
+// four parts, 132 / 129 for two), every part's main slabs come in multiples of three (three weight register
+// sets rotate) and no part starts a pair with an MX slab.  Entries: main slab o = o, MX slab of tap t = 100 + t.
+template <int SS, int PART>
+struct OwnSeq {
     struct Tab {
-        int n;
-        short slab[SLABS * MF], frag[SLABS * MF], index[SLABS * MF];
+        int n, nMain, nX;
+        short slab[27], mainSlab[18], xSlab[9], mainOrd[27], xOrd[27];
     };
-    static constexpr bool active(int s, int f) { return !PERM || EdgeRows::needTap(f, s / 3); }
+    static constexpr int kMaxList = 27;
+    static constexpr Tab make() {
+        int list[kMaxList] = {};
+        int n = 0;
+        auto M = [&](int o) { list[n++] = o; };
+        auto X = [&](int t) { list[n++] = 100 + t; };
+        if (SS == 1) {
+            for (int t = 0; t < 9; ++t) { M(2 * t); M(2 * t + 1); X(t); }
+        } else if (SS == 2 && PART == 0) {
+            X(0); M(0); X(1); M(1); X(2); M(2); X(3); M(3); X(5); M(4); X(6); M(5); X(7); X(8);
+        } else if (SS == 2 && PART == 1) {
+            for (int o = 6; o < 16; ++o) M(o);
+            X(4); M(16); M(17);
+        } else if (SS == 4 && PART == 0) {
+            M(0); X(0); M(1); X(1); M(2); X(2); X(3);
+        } else if (SS == 4 && PART == 1) {
+            M(3); X(4); M(4); X(5); M(5); X(6); X(8);
+        } else if (SS == 4 && PART == 2) {
+            for (int o = 6; o < 12; ++o) M(o);
+        } else if (SS == 4 && PART == 3) {
+            M(12); M(13); M(14); M(15); X(7); M(16); M(17);
+        }
+        Tab t{};
+        t.n = n;
+        for (int u = 0; u < n; ++u) {
+            const bool isx = list[u] >= 100;
+            const int id = isx ? list[u] - 100 : list[u];
+            t.slab[u] = (short)(isx ? 3 * id + 2 : 3 * (id / 2) + (id & 1));
+            t.mainOrd[u] = (short)(isx ? -1 : t.nMain);
+            t.xOrd[u] = (short)(isx ? t.nX : -1);
+            if (isx) t.xSlab[t.nX++] = t.slab[u];
+            else t.mainSlab[t.nMain++] = t.slab[u];
+        }
+        return t;
+    }
+    static constexpr Tab kTab = make();
+    static constexpr int kN = kTab.n, kMain = kTab.nMain, kX = kTab.nX;
+    static constexpr int slab(int u) { return kTab.slab[u]; }           // real slab (M8Seq numbering) at own position u
+    static constexpr int mainOrd(int u) { return kTab.mainOrd[u]; }     // own ordinal of the main slab at u
+    static constexpr int xOrd(int u) { return kTab.xOrd[u]; }           // own ordinal of the MX slab at u
+    static constexpr int mainSlab(int o) { return kTab.mainSlab[o]; }
+    static constexpr int xSlab(int j) { return kTab.xSlab[j]; }
+    // MX records: two register sets.  An even number of own MX slabs runs as one cyclic pipeline across pairs
+    // (the next one is requested at the top of the current one); otherwise the pair's first one is requested at
+    // the top of the pair (set 0 is free once the previous pair's last MX slab has been issued).
+    static constexpr bool kXCyclic = kX >= 2 && kX % 2 == 0;
+    static_assert(kMain % 3 == 0, "three f16 weight sets must carry across chunk pairs");
+    static_assert(kX == 0 || kTab.xOrd[0] < 0 || kXCyclic, "a pair must not start with an MX slab it requests at its top");
+};
+
+// The (own slab, fragment) steps of one chunk pair in issue order, and their inverse: with edge-packed rows
+// the steps whose tap a fragment does not need are left out; the sequence is padded with null steps to a
+// multiple of the fragment window (the window slot of a step must be the same in every pair).
+template <class OS, int MF, bool PERM, int WIN>
+struct StepSeq {
+    static constexpr int kMax = (27 * MF + WIN - 1) / WIN * WIN;
+    struct Tab {
+        int n, padded;
+        short pos[kMax], frag[kMax], index[27 * MF];
+    };
+    static constexpr bool active(int u, int f) { return !PERM || EdgeRows::needTap(f, OS::slab(u) / 3); }
     static constexpr Tab make() {
         Tab t{};
         int n = 0;
-        for (int s = 0; s < SLABS; ++s)
+        for (int u = 0; u < OS::kN; ++u)
             for (int f = 0; f < MF; ++f) {
-                t.index[s * MF + f] = (short)(active(s, f) ? n : -1);
-                if (active(s, f)) {
-                    t.slab[n] = (short)s;
+                t.index[u * MF + f] = (short)(active(u, f) ? n : -1);
+                if (active(u, f)) {
+                    t.pos[n] = (short)u;
                     t.frag[n] = (short)f;
                     ++n;
                 }
             }
-        for (int q = n; q < SLABS * MF; ++q) t.slab[q] = t.frag[q] = 0;
         t.n = n;
+        t.padded = (n + WIN - 1) / WIN * WIN;
+        for (int q = n; q < kMax; ++q) { t.pos[q] = 0; t.frag[q] = -1; }
         return t;
     }
     static constexpr Tab kTab = make();
-    static constexpr int kSteps = kTab.n;
-    static constexpr int slab(int q) { return kTab.slab[q]; }
-    static constexpr int frag(int q) { return kTab.frag[q]; }
-    static constexpr int index(int s, int f) { return kTab.index[s * MF + f]; }
+    static constexpr int kReal = kTab.n;        // steps that issue MFMAs
+    static constexpr int kSteps = kTab.padded;  // ... plus the null steps behind them
+    static constexpr int pos(int q) { return kTab.pos[q]; }
+    static constexpr int frag(int q) { return kTab.frag[q]; } // -1: null step
+    static constexpr int index(int u, int f) { return kTab.index[u * MF + f]; }
 };
 
 // One layer's work for this workgroup.  RES: 0 = no residual, 1 = residual,
@@ -395,8 +464,10 @@ struct StepSeq {
 // per CU: 2.4 MB = 17 us per layer, more than the MFMAs of a one-board tile take); the K split streams
 // it once.  All 2*KS*... chunk tiles of the board are resident in LDS at once (eight image buffers for
 // 256 channels), so the loop has no staging and no barriers.
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1>
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1, int SS = 1, int PART = 0>
 __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
+    static_assert(SS == 1 || (isMx(PREC) && MODE == kConv && SIZE == 2 && MS == 1 && KS == 1 && NWAVES % SS == 0 && PART < SS),
+                  "slab split: two-board MX conv tiles");
     using G = Geom<MODE, SIZE, NWAVES, (isMx(PREC) ? (KS > 1 ? 8 : 4) : 2)>;
     static_assert(KS == 1 || (isMx(PREC) && MODE == kConv && SIZE == 1 && NWAVES % KS == 0),
                   "K split: kF16m8 one-board conv tiles");
@@ -443,7 +514,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         nkc = per;
     }
     const int nft = A.cout / 16;
-    const int waveGroup = (blockIdx.y * NWAVES + wave) / (kRowWG ? KS : MS * KS); // group of NFRAG channel fragments
+    const int waveGroup = (blockIdx.y * NWAVES + wave) / (kRowWG ? KS : MS * KS * SS); // group of NFRAG channel fragments
     const int fBase = (MS > 1) ? (kRowWG ? (int)blockIdx.z : wave % MS) * kMFw : 0; // first row fragment of this wave
     // rows this workgroup may write (a K part past the workgroup's last fragment adds up and converts
     // whatever lies there: with the rows split over workgroups those rows belong to the next one)
@@ -512,9 +583,11 @@ _Pragma("unroll") \
         const int m = kPerm ? (eok ? eb * 81 + ey * 9 + ex : -1) : (fBase + f) * 16 + li; \
         if constexpr (kPerm) { \
             static_assert(NFRAG * 16 * ES == 256, "edge-packed rows: 256-byte row slices (4 rows per instruction)"); \
-            if (wave == 0 && g == 0) \
+            if (wave == 0 && g == 0) { \
                 reinterpret_cast<unsigned*>(smem + G::kRowTabOff)[(f * 4 + (li & 3)) * 4 + (li >> 2)] = \
                     m >= 0 ? (unsigned)m * (unsigned)(A.cout * ES) : ~0u; \
+                if (f == kMFw - 1) reinterpret_cast<unsigned*>(smem + G::kRowTabOff)[(kMFw * 4 + (li & 3)) * 4 + (li >> 2)] = ~0u; \
+            } \
         } \
         if constexpr (G::kBoards) { \
             const int p = kPerm ? (eok ? 24 + eb * 110 + (ey + 1) * 10 + ex : 11) \
@@ -561,21 +634,32 @@ _Pragma("unroll") \
         // slab needs both chunks' tiles in LDS, so there are four image buffers: the pair being
         // computed and the pair being staged.
         using Q = M8Seq<G::kTaps>;
-        static_assert((2 * G::kTaps) % 3 == 0, "three f16 weight sets must carry across chunk pairs");
-        using ST = StepSeq<Q::kSlabs, kMFw, kPerm>;
-        constexpr int kSteps = ST::kSteps; // Q::kSlabs * kMFw, less the (fragment, tap) pairs edge-packed rows leave out
+        using OS = OwnSeq<SS, PART>; // the slabs of a pair this wave runs, in its own order (SS = 1: all 27)
+        static_assert(G::kTaps == 9, "3x3 taps");
         constexpr int kWin = 9, kD = 7;
-        static_assert(kSteps % kWin == 0, "window slot must carry across chunk pairs");
+        using ST = StepSeq<OS, kMFw, kPerm, kWin>;
+        constexpr int kReal = ST::kReal;   // (own slab, fragment) steps that issue MFMAs
+        constexpr int kSteps = ST::kSteps; // ... padded to a multiple of the window: a step's slot is the same in every pair
+        constexpr int kPad = kSteps - kReal;
+        static_assert(kSteps % kWin == 0 && kPad < kD, "window slot must carry across chunk pairs");
         // Next pair's tiles.  All workgroups run in lock-step, so tile loads issued at one point
         // hit HBM/MALL as one burst and take > 2 us; and VMEM loads return in order, so every
         // weight record requested behind them waits that long too.  The items are therefore
-        // requested one per slab, each AFTER its step's weight requests: chunk A' over slabs
-        // 2..7, written to LDS at the top of slab 12; chunk B' over slabs 13..18, written at the
-        // top of slab 25; one barrier per pair, just before the first next-pair fragment request.
-        constexpr int kLoadSlabs = G::kItems < 6 ? G::kItems : 6, kLoadSlabA = 2, kLoadSlabB = 13;
-        constexpr int kBarStep = kSteps - kD;
-        constexpr int kWriteStepA = ST::index(12, 0), kWriteStepB = ST::index(25, 0) < kBarStep ? ST::index(25, 0) : kBarStep - 1;
-        static_assert(ST::index(12, 0) >= 0 && ST::index(25, 0) >= 0, "fragment 0 runs every tap");
+        // requested a few per slab, each AFTER its step's weight requests: chunk A' over own slabs
+        // kLoadA.., written to LDS at the top of own slab kWriteA; chunk B' likewise behind it; one
+        // barrier per pair, just before the first next-pair fragment request.  (All 27 slabs: A' over
+        // slabs 2..7, written at 12; B' over 13..18, written at 25.)
+        constexpr int kOwn = OS::kN;
+        // (short own sequences: all of a chunk's items behind ONE slab's weight requests, three slabs before they are
+        // written -- with a few items per slab over several slabs the last ones had a slab of lead and every pair
+        // waited a tile round trip twice: 12k cycles per pair for 4.2k of MFMAs)
+        constexpr int kLoadSlabs = kOwn >= 20 ? (G::kItems < 6 ? G::kItems : 6) : (kOwn >= 12 ? 3 : 1);
+        constexpr int kLoadSlabA = kOwn >= 20 ? 2 : 0, kWriteA = kOwn >= 20 ? 12 : (kOwn >= 12 ? 6 : 3);
+        constexpr int kLoadSlabB = kOwn >= 20 ? 13 : kWriteA, kWriteB = kOwn >= 20 ? 25 : (kOwn >= 12 ? 12 : kOwn - 1);
+        static_assert(kLoadSlabA + kLoadSlabs <= kWriteA && kLoadSlabB + kLoadSlabs <= kWriteB && kWriteB < kOwn, "tile staging order");
+        constexpr int kBarStep = kReal - kD;
+        constexpr int kWriteStepA = ST::index(kWriteA, 0), kWriteStepB = ST::index(kWriteB, 0) < kBarStep ? ST::index(kWriteB, 0) : kBarStep - 1;
+        static_assert(kWriteStepA >= 0 && ST::index(kWriteB, 0) >= 0 && kWriteStepA < kWriteStepB, "fragment 0 runs every tap");
         static_assert(kWriteStepB < kBarStep, "tile staging order");
         auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
         // MX operand of lane (li, g): 32 fp8 bytes of chunk g>>1 (A / B buffer); g&1 ? lo bytes : hi bytes
@@ -588,12 +672,22 @@ _Pragma("unroll") \
         const u32x4* wc = A.w + lane + (size_t)pair0 * Q::kRecPair * rs;
         const size_t wg4 = (size_t)waveGroup * NFRAG * 64;  // this wave's records inside a main set
         const size_t wg8 = wg4 * 2;                         //                          an MX pair of sets
-        u32x4 w4[3][NFRAG];
-        u32x4 w8[2][NFRAG][2];
+        // weight registers: three sets of f16 records (own main slab o in set o % 3, requested two own main
+        // slabs ahead), two sets of MX records (own MX slab j in set j & 1)
+        u32x4 w4[OS::kMain > 0 ? 3 : 1][NFRAG];
+        u32x4 w8[OS::kX > 0 ? 2 : 1][NFRAG][2];
+        if constexpr (OS::kMain > 0) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int j = 0; j < NFRAG; ++j) w4[o][j] = wc[Q::recOff(Q::slabOfMain(o)) * rs + wg4 + j * 64];
+                for (int j = 0; j < NFRAG; ++j) w4[o][j] = wc[Q::recOff(OS::mainSlab(o)) * rs + wg4 + j * 64];
+        }
+        if constexpr (OS::kXCyclic) {
+#pragma unroll
+            for (int j = 0; j < NFRAG; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) w8[0][j][h] = wc[Q::recOff(OS::xSlab(0)) * rs + wg8 + (j * 2 + h) * 64];
+        }
 
         if constexpr (kStage) {
         // first pair's tiles: both requested up front (the loop's operand registers are not live yet)
@@ -627,12 +721,12 @@ _Pragma("unroll") \
         NSG_STAMP(1);
 
         u32x4 aw[kWin][2];
-        // fragment request of step q (q >= kSteps: the next pair's step q - kSteps)
+        // fragment request of step q (q >= kSteps: the next pair's step q - kSteps; null steps request nothing)
 #define NSG_M8_REQ(QQ, CUR, NXT)                                                                  \
-        {                                                                                         \
+        if (ST::frag((QQ) % kSteps) >= 0) {                                                       \
             const int q_ = (QQ) % kSteps;                                                         \
             const unsigned char* b_ = ((QQ) >= kSteps) ? (NXT) : (CUR);                           \
-            const int s_ = ST::slab(q_), f_ = ST::frag(q_);                                       \
+            const int s_ = OS::slab(ST::pos(q_)), f_ = ST::frag(q_);                              \
             if (Q::isX(s_)) {                                                                     \
                 const unsigned char* ap_ = b_ + abase[f_] + offp8 + tapOff(Q::tap(s_));           \
                 aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(ap_);                        \
@@ -643,8 +737,11 @@ _Pragma("unroll") \
             }                                                                                     \
         }
         const unsigned char* first = kStage ? smem : smem + (size_t)(2 * pair0) * G::kBuf;
+        // Requests run kD steps ahead.  A step whose request would fall on one of the kPad null steps at the
+        // end of the previous pair is requested at the top of its own pair instead (step 0 requests steps
+        // kD - kPad .. kD): the fill before the loop leaves those to it.
 #pragma unroll
-        for (int q = 0; q < kD; ++q) NSG_M8_REQ(q, first, first)
+        for (int q = 0; q < kD - kPad; ++q) NSG_M8_REQ(q, first, first)
 
         for (int kp = 0; kp < npairs; ++kp) {
             const unsigned char* abuf = kStage ? smem + ((2 * kp) & 3) * G::kBuf : smem + (size_t)(2 * (pair0 + kp)) * G::kBuf;
@@ -652,13 +749,17 @@ _Pragma("unroll") \
             const unsigned char* nbuf = kStage ? smem + ((2 * kp + 2) & 3) * G::kBuf
                                                : (kp + 1 < npairs ? abuf + 2 * G::kBuf : abuf);
             [[maybe_unused]] const int nextA = (kp + 1 < npairs) ? 2 * kp + 2 : 2 * kp; // (last pair: harmless re-load)
+            // records of the NEXT pair (the last pair re-reads its own: the buffer's zero padding covers two
+            // record sets past the end, not a whole pair)
+            [[maybe_unused]] const size_t nextRec = (SS == 1 || kp + 1 < npairs) ? (size_t)Q::kRecPair : 0;
             NSG_PIN_ACC_AGPR
 #pragma unroll
-            for (int s = 0; s < Q::kSlabs; ++s) {
+            for (int u = 0; u < kOwn; ++u) {
 #pragma unroll
                 for (int f = 0; f < kMFw; ++f) {
-                    if (!ST::active(s, f)) continue; // (edge-packed rows: this fragment has no neighbours under this tap)
-                    const int q = ST::index(s, f);
+                    if (!ST::active(u, f)) continue; // (edge-packed rows: this fragment has no neighbours under this tap)
+                    const int s = OS::slab(u);
+                    const int q = ST::index(u, f);
 #ifdef NSG_DIAG_SLABS
                     // slab timeline of workgroup 0 / wave 0, stored behind the per-workgroup stamps
                     // (its s_memtime drains the fragment window: a separate diagnostic build)
@@ -668,31 +769,41 @@ _Pragma("unroll") \
                     if (kStage && q == kWriteStepA) { NSG_STAGE_WRITE((2 * kp + 2) & 3) }
                     if (kStage && q == kWriteStepB) { NSG_STAGE_WRITE((2 * kp + 3) & 3) }
                     if (kStage && q == kBarStep) __syncthreads(); // publishes the two tiles written above
-                    // MX records: two sets.  X0 is requested at the top of the pair (set 0 is free once
-                    // the previous pair's last MX slab is done), X_t+1 at the top of X_t.
-                    const bool reqX = (s == 0) || (Q::isX(s) && Q::tap(s) + 1 < G::kTaps);
+                    // MX records, two sets: cyclic (the next own MX slab, the next pair's first behind the last, is
+                    // requested at the top of the current one), or the pair's first at the top of the pair (set 0 is
+                    // free once the previous pair's last MX slab is done) and X_j+1 at the top of X_j.
+                    const int xj = OS::xOrd(u);
+                    const bool reqX = OS::kXCyclic ? xj >= 0 : ((u == 0 && OS::kX > 0) || (xj >= 0 && xj + 1 < OS::kX));
                     if (f == 0) {
-                        if (!Q::isX(s)) { // f16 record two main slabs ahead (beyond this pair: the next pair's)
-                            const int o2 = Q::mainOrd(s) + 2;
-                            const size_t o = (o2 >= 2 * G::kTaps ? Q::kRecPair : 0) + Q::recOff(Q::slabOfMain(o2 % (2 * G::kTaps)));
+                        if (!Q::isX(s)) { // f16 record two own main slabs ahead (beyond this pair: the next pair's)
+                            const int o2 = OS::mainOrd(u) + 2;
+                            const size_t o = (o2 >= OS::kMain ? nextRec : 0) + Q::recOff(OS::mainSlab(o2 % (OS::kMain > 0 ? OS::kMain : 1)));
 #pragma unroll
                             for (int j = 0; j < NFRAG; ++j) w4[o2 % 3][j] = wc[o * rs + wg4 + j * 64];
                         }
                         if (reqX) {
-                            const int t2 = (s == 0) ? 0 : Q::tap(s) + 1;
-                            const size_t o = Q::recOff(Q::slabOfX(t2));
+                            const int j2 = OS::kXCyclic ? xj + 1 : ((u == 0 && xj != 0) ? 0 : xj + 1);
+                            const size_t o = ((OS::kXCyclic && j2 >= OS::kX) ? nextRec : 0) + Q::recOff(OS::xSlab(j2 % (OS::kX > 0 ? OS::kX : 1)));
 #pragma unroll
                             for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
-                                for (int h = 0; h < 2; ++h) w8[t2 & 1][j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
+                                for (int h = 0; h < 2; ++h) w8[j2 & 1][j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
                         }
                     }
-                    const bool loadA = kStage && f == 0 && s >= kLoadSlabA && s < kLoadSlabA + kLoadSlabs;
-                    const bool loadB = kStage && f == 0 && s >= kLoadSlabB && s < kLoadSlabB + kLoadSlabs;
+                    const bool loadA = kStage && f == 0 && u >= kLoadSlabA && u < kLoadSlabA + kLoadSlabs;
+                    const bool loadB = kStage && f == 0 && u >= kLoadSlabB && u < kLoadSlabB + kLoadSlabs;
                     if (loadA || loadB) {
 #pragma unroll
-                        for (int k = s - (loadA ? kLoadSlabA : kLoadSlabB); k < G::kItems; k += kLoadSlabs)
+                        for (int k = u - (loadA ? kLoadSlabA : kLoadSlabB); k < G::kItems; k += kLoadSlabs)
+#ifdef NSG_EXP_RUNTIME // bit 2 (timing only, wrong results): every in-loop tile item re-reads one hot line
+                            if (A.exp & 4) st[k] = *reinterpret_cast<const u32x4*>(A.x + lane * 16);
+                            else
+#endif
                             st[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)(nextA + (loadB ? 1 : 0)) * 128);
+                    }
+                    if (q == 0) {
+#pragma unroll
+                        for (int r = kD - kPad; r < kD; ++r) NSG_M8_REQ(r, abuf, nbuf)
                     }
                     NSG_M8_REQ(q + kD, abuf, nbuf)
                     const int slot = q % kWin;
@@ -701,8 +812,8 @@ _Pragma("unroll") \
                                                                  __builtin_bit_cast(i32x4_t, aw[slot][1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                         for (int j = 0; j < NFRAG; ++j) {
-                            const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[Q::tap(s) & 1][j][0]),
-                                                                     __builtin_bit_cast(i32x4_t, w8[Q::tap(s) & 1][j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+                            const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[xj & 1][j][0]),
+                                                                     __builtin_bit_cast(i32x4_t, w8[xj & 1][j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
                             if constexpr (kM6) // e2m3 x e2m3; dword 6 of either operand block carries its E8M0 exponent in byte 0
                                 acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 2, 2, 0, wa[6], 0, xb[6]);
                             else
@@ -713,13 +824,15 @@ _Pragma("unroll") \
 #pragma unroll
                         for (int j = 0; j < NFRAG; ++j)
                             acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                __builtin_bit_cast(f16x8, w4[Q::mainOrd(s) % 3][j]), __builtin_bit_cast(f16x8, aw[slot][0]), acc[f][j], 0, 0, 0);
+                                __builtin_bit_cast(f16x8, w4[OS::mainOrd(u) % 3][j]), __builtin_bit_cast(f16x8, aw[slot][0]), acc[f][j], 0, 0, 0);
                     }
                     // issue order inside the step: the first MFMA, then the requests (they issue in its
                     // shadow instead of between two steps), then the other MFMAs
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (Q::isX(ST::slab((q + kD) % kSteps))) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (ST::frag((q + kD) % kSteps) >= 0) {
+                        if (Q::isX(OS::slab(ST::pos((q + kD) % kSteps)))) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
                     if (f == 0 && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, NFRAG, 0);
                     if (f == 0 && reqX) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NFRAG, 0);
                     if (loadA || loadB) __builtin_amdgcn_sched_group_barrier(0x020, (G::kItems + kLoadSlabs - 1) / kLoadSlabs, 0);
@@ -756,6 +869,45 @@ _Pragma("unroll") \
                     acc[f][j] = sum;
                 }
             __syncthreads(); // the staging regions of the epilogue overlap the exchange area
+        }
+        if constexpr (SS > 1) {
+            // Sum the slab parts: the SS waves of a channel group publish their accumulators in LDS and
+            // wave `PART` keeps the row fragments PART*kMFe .. +kMFe-1, added up in part order
+            // (deterministic).  Eleven fragments of four waves are 176 KiB: two rounds of six fragments.
+            constexpr int kMFe = (kMFw + SS - 1) / SS, kFR = 6;
+            static_assert(kFR % kMFe == 0 && 2 * kFR >= kMFw && NWAVES * kFR * NFRAG * 1024 <= G::kLds, "exchange rounds");
+            u32x4* xb = reinterpret_cast<u32x4*>(smem);
+            const int w0 = wave - PART; // first wave of this channel group
+            f32x4 mine[kMFe][NFRAG];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int f = r * kFR; f < (r + 1) * kFR && f < kMFw; ++f)
+#pragma unroll
+                    for (int j = 0; j < NFRAG; ++j)
+                        xb[((wave * kFR + (f - r * kFR)) * NFRAG + j) * 64 + lane] = __builtin_bit_cast(u32x4, acc[f][j]);
+                __syncthreads();
+                if (PART * kMFe >= r * kFR && PART * kMFe < (r + 1) * kFR) {
+#pragma unroll
+                    for (int fe = 0; fe < kMFe; ++fe)
+#pragma unroll
+                        for (int j = 0; j < NFRAG; ++j) {
+                            const int gf = PART * kMFe + fe; // (past the tile: zeros, its rows are masked anyway)
+                            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (gf < kMFw) {
+#pragma unroll
+                                for (int p2 = 0; p2 < SS; ++p2)
+                                    sum += __builtin_bit_cast(f32x4, xb[(((w0 + p2) * kFR + (gf - r * kFR)) * NFRAG + j) * 64 + lane]);
+                            }
+                            mine[fe][j] = sum;
+                        }
+                }
+                __syncthreads(); // the next round (or the epilogue's staging regions) overwrites the exchange area
+            }
+#pragma unroll
+            for (int fe = 0; fe < kMFe; ++fe)
+#pragma unroll
+                for (int j = 0; j < NFRAG; ++j) acc[fe][j] = mine[fe][j];
         }
     } else {
     // weight stream: record q = (kc*taps + tap)*2 + s, NFRAG 1-KiB records per wave, held
@@ -1077,8 +1229,9 @@ _Pragma("unroll") \
 #endif
     if constexpr (MODE == kConv && NFRAG == 4) {
         // (K split: after the exchange a wave owns kMFe of the row fragments, from fBaseE on)
-        constexpr int kMFe = (kMFw + KS - 1) / KS;
-        const int fBaseE = fBase + ((KS > 1) ? (wave % KS) * kMFe : 0);
+        constexpr int kParts = KS > 1 ? KS : SS;
+        constexpr int kMFe = (kMFw + kParts - 1) / kParts;
+        const int fBaseE = fBase + ((KS > 1) ? (wave % KS) * kMFe : PART * kMFe);
         // ---- convolution epilogue, staged through LDS so that every global access is
         // a full-line, lane-linear 16-byte access.  In the MFMA result layout a lane
         // owns 16 channels of ONE row, so a direct store scatters 16-byte pieces over
@@ -1117,24 +1270,26 @@ _Pragma("unroll") \
         const int lpc = lane % kPPR;    //                   piece within the row
         // global addresses = wave-uniform row base (scalar arithmetic) + one per-lane 32-bit offset
         const unsigned laneOff = (unsigned)lrow * (unsigned)rowBytes + (unsigned)lpc * 16u;
-        const size_t tileOff = (row0 + (size_t)fBaseE * 16) * rowBytes + sliceOff;
+        const size_t tileOff = (row0 + (kPerm ? (size_t)0 : (size_t)fBaseE * 16)) * rowBytes + sliceOff; // (edge-packed: the table holds offsets inside the tile)
         const unsigned char* resBase = A.res + tileOff;
         unsigned char* yBase = A.y + tileOff;
         // edge-packed rows: per-lane offsets of the four rows (it = 0..3) this lane moves for fragment f
         [[maybe_unused]] const unsigned permLane = (unsigned)lpc * 16u;
+        constexpr int kFBasePerm = PART * kMFe; // (edge-packed tiles have no K split: the first fragment is static)
         auto rowOffs = [&](int f) -> u32x4 {
-            if constexpr (kPerm) return *reinterpret_cast<const u32x4*>(smem + G::kRowTabOff + (f * 4 + lrow) * 16);
+            if constexpr (kPerm) return *reinterpret_cast<const u32x4*>(smem + G::kRowTabOff + ((kFBasePerm + f) * 4 + lrow) * 16);
             else return u32x4{0u, 0u, 0u, 0u};
         };
         // (ok, byte offset from resBase / yBase) of row it*kRPI + lrow of fragment f
         auto rowOk = [&](int f, int it, const u32x4& ro) -> bool {
-            if constexpr (kPerm) return f != EdgeRows::kMF - 1 || ro[it] != ~0u; // only the last fragment has padding rows
+            if constexpr (kPerm) return kFBasePerm + f < EdgeRows::kMF - 1 || ro[it] != ~0u; // only the last fragment (and what lies past the tile) has padding rows
             else return (fBaseE + f) * 16 + it * kRPI + lrow < rowLimit;
         };
         auto rowByte = [&](int f, int it, const u32x4& ro) -> size_t {
             if constexpr (kPerm) return (size_t)(ro[it] + permLane);
             else return (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff;
         };
+        static_assert(!kPerm || KS == 1, "edge-packed rows: no K split");
 
         // Most of this wave's residual slice is requested up front (the main loop's operand registers
         // are dead), so the fragment pipeline below does not wait a global round trip per fragment.
@@ -1467,7 +1622,7 @@ _Pragma("unroll") \
     }
 }
 
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES, int MS = 1, int KS = 1>
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, bool HAS_RES, int MS = 1, int KS = 1, int SS = 1>
 __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, NFRAG, PREC>())) void tileKernel(
     // The fourteen dwords every conv prologue needs come first as plain arguments: the build
     // preloads them into SGPRs at wave launch (-amdgpu-kernarg-preload-count, a by-value struct
@@ -1478,7 +1633,19 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<MODE, SIZE, NWAVES, N
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Args A{x, w, bias, res, y, T.policy, T.vfeat, kdim, cout, T.totalRows, flags & 1, T.valueChannels,
                  T.vfeatStride, accScale, (flags >> 1) & 1, T.kSplits, T.partStride, T.stamps, flags >> 2};
-    tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS>(A, smem, true);
+    if constexpr (SS == 1) {
+        tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS>(A, smem, true);
+    } else {
+        // slab split: the SS waves of a channel group run different static instruction streams (their own
+        // slabs of every chunk pair); every path meets the same workgroup barriers in the same order
+        const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) % SS;
+        if (part == 0) tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS, SS, 0>(A, smem, true);
+        else if (part == 1) tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS, SS, 1>(A, smem, true);
+        else if constexpr (SS > 2) {
+            if (part == 2) tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS, SS, 2>(A, smem, true);
+            else tileBody<PREC, MODE, SIZE, NFRAG, NWAVES, HAS_RES ? 1 : 0, MS, KS, SS, 3>(A, smem, true);
+        }
+    }
 }
 
 // Persistent trunk: one launch runs every 3x3 layer (stem + 2 per residual block)
@@ -1515,11 +1682,11 @@ inline int expFlags() { const char* e = getenv("NSG_EXP_FLAGS"); return e ? atoi
 constexpr int expFlags() { return 0; }
 #endif
 
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int MS = 1, int KS = 1>
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int MS = 1, int KS = 1, int SS = 1>
 hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
     using G = Geom<MODE, SIZE, NWAVES, (isMx(PREC) ? (KS > 1 ? 8 : 4) : 2)>;
     constexpr bool kRowWG = (MS > 1 && KS > 1); // row groups as workgroups (grid z), see tileBody
-    constexpr int kChanGroups = NWAVES / (kRowWG ? KS : MS * KS);
+    constexpr int kChanGroups = NWAVES / (kRowWG ? KS : MS * KS * SS);
     const int gy = a.cout / (kChanGroups * NFRAG * 16);
     if (gy < 1 || gy * kChanGroups * NFRAG * 16 != a.cout) return hipErrorInvalidValue;
     if (KS > 1) { // every chunk tile resident: at most eight, and whole pairs for every K part
@@ -1528,7 +1695,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
     }
     hipError_t err;
     if (MODE == kConv && a.res) {
-        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, (MODE == kConv), MS, KS>;
+        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, (MODE == kConv), MS, KS, SS>;
         static std::atomic<int> attrDevMask{0}; // per kernel instantiation: devices whose attribute is set
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1540,7 +1707,7 @@ hipError_t launchOne(const Args& a, int gridX, hipStream_t stream) {
         hipLaunchKernelGGL(k, dim3(gridX, gy, kRowWG ? MS : 1), dim3(G::kThreads), G::kLdsAlloc, stream, a.x, a.w, a.res, a.y, a.bias,
                            a.kdim, a.cout, (a.relu ? 1 : 0) | (a.outF16x3 ? 2 : 0) | expFlags(), a.accScale, tailOf(a));
     } else {
-        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false, MS, KS>;
+        auto k = tileKernel<PREC, MODE, SIZE, NFRAG, NWAVES, false, MS, KS, SS>;
         static std::atomic<int> attrDevMask{0};
         int dev = 0;
         (void)hipGetDevice(&dev);

@@ -18,6 +18,7 @@ ConvTuning readConvTuning() {
     if (const char* e = getenv("NSG_ROWSPLIT8_MAX_BATCH")) t.rowsplit8Max = atoi(e);
     if (const char* e = getenv("NSG_SPLIT_BATCH")) t.splitBatch = atoi(e);
     if (const char* e = getenv("NSG_SPLIT_BATCH_MAX")) t.splitBatchMax3 = atoi(e);
+    if (const char* e = getenv("NSG_SLAB_SPLIT")) t.slabSplit = atoi(e);
     return t;
 }
 
@@ -132,7 +133,7 @@ void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfra
 }
 
 bool canRunTrunk(int cout, const ConvPlan& plan) {
-    return plan.nfrag == kNfrag && plan.msplit == 1 && plan.ksplit == 1 && cout == plan.nwaves * 64 &&
+    return plan.nfrag == kNfrag && plan.msplit == 1 && plan.ksplit == 1 && plan.sslab == 1 && cout == plan.nwaves * 64 &&
            (plan.nwaves == 4 || plan.nwaves == 3);
 }
 

@@ -532,6 +532,29 @@ nsg::ConvPlan planForBatch(nsg_evaluator* ev, int B) {
         }
     }
 
+    // Mid batches, MX arithmetic: two-board tiles of ONE 64-channel group (or two) per workgroup whose waves split
+    // every chunk pair's slabs between them (mfma_tile.h, OwnSeq) -- where one workgroup per (two boards, group)
+    // fills more than half the CUs in one round and the four-workgroups-per-board K split does not apply.  Against
+    // the one-board tiles it replaces: a workgroup streams half the weights for twice the boards, and the
+    // two-board tile's edge-packed rows need 19 % fewer matrix instructions per board.  MEASURED SLOWER (round 3,
+    // profiles/r03/d_*): 113k against 123k evals/s at 128 boards, 134k against 151k at 256 -- a wave's share of a
+    // chunk pair is 4.2k cycles of MFMAs, and the pair's two tile round trips, its barrier and the one-slab lead of
+    // the MX weight records no longer hide behind it.  Opt-in: NSG_SLAB_SPLIT=1.
+    if (mx && ev->tuning.slabSplit == 1 && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 && ev->tuning.nwaves == 0 &&
+        ev->tuning.msplit == 0 && !(plan.ksplit == 4)) {
+        const long cus = ev->prop.multiProcessorCount;
+        const long tiles = (B + 1) / 2;
+        for (int ss : {4, 2}) {
+            if (ev->F % (256 / ss) != 0) continue;
+            const long wgs = tiles * (ev->F / (256 / ss));
+            if (wgs <= cus && wgs * 2 > cus) {
+                plan = nsg::ConvPlan{};
+                plan.nb = 2; plan.nfrag = 4; plan.nwaves = 4; plan.sslab = ss;
+                break;
+            }
+        }
+    }
+
     return plan;
 }
 
@@ -772,7 +795,8 @@ static int checkTuningEnv() {
         {"NSG_ROWSPLIT8_MAX_BATCH", 0, 65535, "largest batch of the four-way K split with two row groups"},
         {"NSG_SPLIT_BATCH", 0, 1, "full part + remainder batches"},
         {"NSG_SPLIT_BATCH_MAX", 0, 64, "largest batch (quarters of the CU count) that starts with a full chip of two-board tiles"}, {"NSG_ROCTX", 0, 1, "profiler markers"},
-        {"NSG_SHARED_FORCE_COPY", 0, 1, "nsg_load_shared copies even on one device"}};
+        {"NSG_SHARED_FORCE_COPY", 0, 1, "nsg_load_shared copies even on one device"},
+        {"NSG_SLAB_SPLIT", 0, 1, "slab-split two-board tiles at mid batches"}};
     for (const Var& v : vars) {
         const char* e = getenv(v.name);
         if (!e) continue;
@@ -1328,6 +1352,12 @@ int nsg_get_last_split(nsg_evaluator* ev, int* row_split, int* k_split) {
     if (!ev) return fail(NSG_E_INVALID, "null evaluator");
     if (row_split) *row_split = ev->lastPlan.nb ? ev->lastPlan.msplit : 0;
     if (k_split) *k_split = ev->lastPlan.nb ? ev->lastPlan.ksplit : 0;
+    return NSG_OK;
+}
+
+int nsg_get_last_slab_split(nsg_evaluator* ev, int* slab_split) {
+    if (!ev || !slab_split) return fail(NSG_E_INVALID, "null argument");
+    *slab_split = ev->lastPlan.nb ? ev->lastPlan.sslab : 0;
     return NSG_OK;
 }
 

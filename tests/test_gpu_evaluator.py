@@ -798,3 +798,43 @@ def test_custom_features_v1_93_planes(nsg, oracle, monkeypatch, precision, tol):
     with pytest.raises(nsg.NsgError, match="93 input planes"):
         ev.load_memory(blob)
     ev.close()
+
+
+@pytest.mark.parametrize("mx", ["f16m8", "f16m6"])
+@pytest.mark.parametrize("channels,batch,ss", [(256, 65, 4), (256, 101, 4), (256, 128, 4), (256, 129, 2), (256, 200, 2),
+                                               (256, 256, 2), (192, 100, 4), (384, 70, 4), (128, 250, 4)])
+def test_slab_split_tiles(nsg, oracle, monkeypatch, channels, batch, ss, mx):
+    """Mid batches in the MX arithmetic: two-board tiles of one (or two) 64-channel groups per workgroup whose
+    waves split every chunk pair's SLABS between them -- each wave runs its own static subset of the 27 slabs
+    for all eleven edge-packed row fragments, the group adds its accumulators up through LDS in two rounds.
+    Against the oracle, against the f16x3 evaluator on EVERY board, and against the plans these tiles replace
+    (NSG_SLAB_SPLIT=0: one-board tiles, K split): the f32 sums differ by summation order only."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    wgs = ((batch + 1) // 2) * (channels // (256 // ss))
+    if not (wgs <= cus < 2 * wgs) or (ss == 2 and ((batch + 1) // 2) * (channels // 64) <= cus) or \
+            (channels == 256 and batch * 4 <= cus):
+        pytest.skip("batch range of this plan depends on the CU count")
+    monkeypatch.setenv("NSG_SPLIT_BATCH", "0")  # one plan for the whole batch (129 would run as 128 + 1)
+    monkeypatch.setenv("NSG_SLAB_SPLIT", "1")   # opt-in: measured slower than the plans it would replace (DESIGN.md 4.2)
+    ev, blob = make(nsg, 3, channels, batch, precision=mx, seed=163)
+    bb = nsg.synth.random_batch(batch, 86, seed=164, garbage=True)
+    p, v, d = ev.compute_blocking(bb)
+    plan = ev.last_plan()
+    assert plan["trunk_precision"] == mx and plan["boards_per_group"] == 2 and plan["slab_split"] == ss, plan
+    idx = sorted({0, 1, batch // 2, batch - 2, batch - 1})
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
+    x3, _ = make(nsg, 3, channels, batch, precision="f16x3", seed=163)
+    p3, v3, d3 = x3.compute_blocking(bb)
+    assert float(np.abs(p - p3).max()) < TOL and float(np.abs(v - v3).max()) < TOL and float(np.abs(d - d3).max()) < TOL
+    monkeypatch.setenv("NSG_SLAB_SPLIT", "0")
+    old, _ = make(nsg, 3, channels, batch, precision=mx, seed=163)
+    po, vo, do = old.compute_blocking(bb)
+    assert old.last_plan()["slab_split"] == 1
+    assert float(np.abs(p - po).max()) < 3e-4 and float(np.abs(v - vo).max()) < 1e-4 and float(np.abs(d - do).max()) < 1e-4
+    # slot independence: the same boards in another order give the same bits
+    perm = np.random.default_rng(5).permutation(batch)
+    p2, v2, d2 = ev.compute_blocking(bb[perm])  # (the tuning variables were read when `ev` was created)
+    np.testing.assert_array_equal(p2, p[perm])
+    np.testing.assert_array_equal(v2, v[perm])
