@@ -166,6 +166,23 @@ def conv_mfma_busy(d):
     return sum(v) / len(v) if v else None
 
 
+def extract_traffic(B):
+    """HBM bytes per extractNCHW launch from the committed PMC passes (scripts/pmc_extract.sh), newest round
+    first: (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per the guide's gfx950 correction."""
+    if B != 512:
+        return None, None
+    for rnd in ("r03",):
+        rel = os.path.join("profiles", rnd, "pmc_extract_summary.json")
+        try:
+            d = json.load(open(os.path.join(ROOT, rel)))
+        except (OSError, ValueError):
+            continue
+        for name, c in d.items():
+            if "extractNCHW" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, rel
+    return None, None
+
+
 def extract_roofline(nsg, bb, B):
     """Second roofline entry: the plane-expansion kernel alone, HBM-bound.
     Algorithmic bytes per position = 1376 read + 27 864 written.  Timed live with HIP events on
@@ -190,8 +207,11 @@ def extract_roofline(nsg, bb, B):
         out[name] = e0.elapsed_time(e1) / iters
     nbytes = B * (1376 + 27864)
     ms = out["NCHW"]
+    traffic, traffic_file = extract_traffic(B)
     return {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
-            "frac": nbytes / ms / 1e6 / 8000.0, "traffic": None,
+            "frac": nbytes / ms / 1e6 / 8000.0, "traffic": traffic,
+            "traffic_source": (f"{traffic_file} (committed rocprofv3 --pmc passes of this kernel at this batch, NOT "
+                               f"measured by this run)" if traffic_file else None),
             "kernel": "extractNCHW (nsg_extract_bits, channels first; the reference's K1)",
             "avg_launch_ms": ms, "launches_timed": 200, "algorithmic_bytes_per_launch": nbytes,
             "nhwc_avg_launch_ms": out["NHWC"], "nhwc_GB_per_s": nbytes / out["NHWC"] / 1e6,
@@ -688,7 +708,7 @@ def main():
                 big.load_memory(blob)
                 big.upload_features(nsg.positions.startpos_batch(1024))
                 by_batch = {}
-                for nb in (1, 64, 128, 256, 1024):  # 128 = the engine's default BatchSize (context.h:79)
+                for nb in (1, 8, 32, 64, 128, 256, 1024):  # 128 = the engine's default BatchSize (context.h:79)
                     rate, n, took = held_rate(lambda: big.forward_resident(nb), nb, torch.cuda.synchronize, 1.0)
                     by_batch[str(nb)] = rate
                 by_batch["512"] = value
@@ -696,6 +716,14 @@ def main():
                 # ... and as a fraction of the MFMA roofline (north_star: "as absolute numbers and as fraction
                 # of the MFMA roofline"): evals/s x algorithmic flops per position / the f16 dense peak
                 out["frac_of_mfma_roofline_by_batch"] = {k: v * flops_pos / 1e12 / peak for k, v in by_batch.items()}
+                # small batches are bound by the WEIGHT stream, not by MFMA: every forward reads every packed trunk
+                # record once (4 bytes per weight as packed: f16 + two e2m3 copies + exponents / padding), so the roof
+                # is forwards/s x packed bytes against the 8 TB/s of HBM (the weights sit in the 256 MB Infinity Cache
+                # between forwards; HBM is the conservative roof)
+                wbytes = 4.0 * 9 * (128 * channels + 2 * blocks * channels * channels)
+                out["packed_trunk_weight_bytes_per_forward"] = wbytes
+                out["frac_of_weight_bw_roofline_by_batch"] = {k: (v / int(k)) * wbytes / 8e12 for k, v in by_batch.items()
+                                                              if int(k) <= 64}
                 big.close()
             out["roofline_extract"] = extract_roofline(nsg, bb, B)
         if not args.no_host_path and world == 1:
