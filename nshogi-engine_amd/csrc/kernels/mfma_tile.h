@@ -73,11 +73,7 @@ template <int MODE, int SIZE, int NWAVES, int NBUF = 2>
 struct Geom {
     static constexpr bool kBoards = (MODE == kConv);
     static constexpr int kRows = kBoards ? SIZE * 81 : SIZE * 16;
-#ifdef NSG_EXP_DROP_TAIL_FRAGMENT // timing-only (wrong results): a two-board tile without its 11th, 2-row fragment
-    static constexpr int kMF = (kBoards && SIZE == 2) ? 10 : (kRows + 15) / 16;
-#else
     static constexpr int kMF = (kRows + 15) / 16;
-#endif
     static constexpr int kEntries = kBoards ? SIZE * 110 + 24 : kMF * 16;
     static constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
     static constexpr int kBuf = 8 * kPlane;  // one 128-byte channel chunk
