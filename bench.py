@@ -418,6 +418,9 @@ def main():
     ap.add_argument("--selfplay-solver-threads", type=int, default=4)
     ap.add_argument("--selfplay-games-per-group", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-sample", action="store_true",
+                    help="no rocm-smi child processes during the sustained leg (under rocprofv3 the box refuses a "
+                         "profiled process's children that exec another program)")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--executor", default="hip", choices=["hip", "random"],
                     help="hip: the MI355X evaluator (the benchmark).  random: CPU rehearsal of the multi-rank path -- "
@@ -506,7 +509,9 @@ def main():
         import threading
         clock_samples, clock_stop = [], threading.Event()
         sampler = None
-        if rank == 0:  # the chip runs this kernel power-limited: the clock it HOLDS under the load is sampled live
+        profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+        if rank == 0 and not args.no_clock_sample and not profiled:
+            # the chip runs this kernel power-limited: the clock it HOLDS under the load is sampled live
             sampler = threading.Thread(target=sample_clock, args=(local_rank, clock_samples, clock_stop), daemon=True)
             sampler.start()
         rate, n, secs = held_rate(lambda: ev.forward_resident(B), B, torch.cuda.synchronize, args.sustain_seconds)

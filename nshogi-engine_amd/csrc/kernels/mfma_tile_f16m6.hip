@@ -8,10 +8,12 @@ namespace tile {
 hipError_t launchConvF16m6(const Args& a, int batch, const ConvPlan& p, hipStream_t s) {
     const int gx = (batch + p.nb - 1) / p.nb;
     if (p.nfrag != 4) return hipErrorInvalidValue;
+#ifndef NSG_NO_SLAB_SPLIT // (a build without the opt-in slab-split instantiations: make ab ABFLAGS=-DNSG_NO_SLAB_SPLIT)
     // mid batches, two boards per workgroup: the four waves are one 64-channel group whose waves split every chunk
     // pair's slabs four ways, or two groups of two (mfma_tile.h, OwnSeq)
     if (p.sslab == 4 && p.nb == 2 && p.nwaves == 4) return launchOne<kF16m6, kConv, 2, 4, 4, 1, 1, 4>(a, gx, s);
     if (p.sslab == 2 && p.nb == 2 && p.nwaves == 4) return launchOne<kF16m6, kConv, 2, 4, 4, 1, 1, 2>(a, gx, s);
+#endif
     if (p.sslab != 1) return hipErrorInvalidValue;
     // mid batches: one board per workgroup, two wave groups on three row fragments each
     // ... or, where all the board's chunk tiles fit in LDS at once, two K halves on all six row fragments

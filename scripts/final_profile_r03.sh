@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/final_r03
 mkdir -p $OUT
 python3 bench.py > $OUT/f_bench_default_f16m6.json 2> $OUT/bench_default.err; echo "bench default: $?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --selfplay-seconds 0 --no-cpu-baseline --no-host-path --steps 40 --warmup 10 > $OUT/j_bench_f16m6_under_rocprof_40steps.json 2> $OUT/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --selfplay-seconds 0 --no-cpu-baseline --no-host-path --no-clock-sample --steps 40 --warmup 10 > $OUT/j_bench_f16m6_under_rocprof_40steps.json 2> $OUT/kt.err
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/j_f16m6_b512_20x256_kernel_stats_40steps.csv; echo "kernel trace: $?"
 rm -rf $OUT/kt
 scripts/pmc.sh r03_f16m6 --selfplay-seconds 0 > $OUT/pmc.log 2>&1 && python3 scripts/pmc_summary.py gpurun_out/pmc_r03_f16m6 > $OUT/pmc_f16m6_conv_top.txt && cp gpurun_out/pmc_r03_f16m6/summary.json $OUT/pmc_f16m6_summary.json; echo "pmc: $?"
