@@ -123,6 +123,30 @@ bool canRunTrunk(int cout, const ConvPlan& plan);
 hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
                        const ConvPlan& plan, hipStream_t stream);
 
+// Team trunk (team_trunk.hip): every 3x3 layer of up to eight boards in ONE persistent launch, a board per team of
+// 32 workgroups that hand activations to each other through agent-scope stores / loads and one counter per team.
+// kF16x3 arithmetic, records and activation layout; 256 trunk channels.  `counters`: 8 x 8 u64 (one 64-byte line
+// per team), monotonic over the evaluator's lifetime: bases.v[t] = the value team t's counter holds before the
+// launch; the launch adds (nLayers - 1) * 32 to the counters of teams 0 .. boards-1.  `status`: a host-mapped int
+// the kernel raises when a bounded spin runs out.
+typedef unsigned int team_u32x4 __attribute__((ext_vector_type(4)));
+struct TeamLayer {
+    const unsigned char* x;   // [boards][81][kdim] kF16x3
+    const team_u32x4* w;      // kF16x3 records of the layer (packTileWeights)
+    const float* bias;        // [cout]
+    const unsigned char* res; // residual, layout of y, or null
+    unsigned char* y;         // [boards][81][cout] kF16x3
+    int kdim, cout, relu;
+    float accScale;
+};
+struct TeamBases { unsigned long long v[8]; };
+bool teamTrunkSupports(int channels, int stemKdim, int boards);
+#ifdef TEAM_STAMPS
+void teamTrunkDumpStamps(); // diagnostic builds: per-phase cycles of one member, printed when an evaluator is destroyed
+#endif
+hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, unsigned long long* counters,
+                           const TeamBases& bases, int* status, hipStream_t stream);
+
 // Policy 1x1 conv (27 ch, +bias, raw logits -> policy[b][c*81+sq] f32) and
 // value-feature 1x1 conv (VC ch, folded-BN bias, ReLU -> vfeat[b*vfeatStride + sq*VC+c] T)
 // as ONE GEMM over coutPadded = roundup(VC+27, 64) channels ordered

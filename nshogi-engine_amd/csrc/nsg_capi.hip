@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <string>
 #include <thread>
@@ -311,6 +312,17 @@ struct nsg_evaluator {
 
     void* trunkOut = nullptr; // which act[] holds the trunk output of the last forward
 
+    // Team trunk (kernels/team_trunk.hip): up to eight boards, every 3x3 layer in one persistent launch, kF16x3
+    // arithmetic.  NSG_TEAM_TRUNK=0 switches it off.  One team launch per DEVICE at a time (teamToken below).
+    DevBuf teamLayers;       // nsg::TeamLayer list (stem + 2 per block) on the kF16x3 copy of the trunk
+    DevBuf teamCounters;     // 8 x 64 B: one monotonic 64-bit counter per team
+    int teamLayerCount = 0;
+    int teamEnabled = 1;
+    nsg::TeamBases teamBases{};
+    int* teamStatusHost = nullptr; // host-mapped: raised by the kernel when a bounded spin runs out
+    int* teamStatusDev = nullptr;
+    bool teamLast = false;   // the most recent forward ran the team trunk
+
     // chains: large batches run as independent half-batch launch chains
     static constexpr int kMaxChains = 4;
     hipStream_t chainStream[kMaxChains - 1] = {};
@@ -419,6 +431,54 @@ int roundUp(int a, int b) { return (a + b - 1) / b * b; }
 __global__ void delayKernel(unsigned long long ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+// Two team launches on one device could each hold CUs that the other's not-yet-scheduled members need.  One token
+// per device: an evaluator may launch a team trunk if it holds the token already (its launches are ordered on its
+// own stream) or if the holder's stream is idle; otherwise this forward runs the per-layer kernels.
+std::mutex gTeamMutex;
+nsg_evaluator* gTeamOwner[64] = {};
+bool acquireTeamToken(nsg_evaluator* ev) {
+    std::lock_guard<std::mutex> lock(gTeamMutex);
+    nsg_evaluator*& owner = gTeamOwner[ev->gpu & 63];
+    if (owner == ev) return true;
+    if (owner != nullptr && hipStreamQuery(owner->stream) != hipSuccess) return false;
+    owner = ev;
+    return true;
+}
+void releaseTeamToken(nsg_evaluator* ev) {
+    std::lock_guard<std::mutex> lock(gTeamMutex);
+    if (gTeamOwner[ev->gpu & 63] == ev) gTeamOwner[ev->gpu & 63] = nullptr;
+}
+
+// The whole forward of a batch of at most eight boards with the team trunk.
+int enqueueTeam(nsg_evaluator* ev, int B, hipStream_t s, hipEvent_t trunkBegin, hipEvent_t trunkEnd) {
+    const int prec = nsg::kF16x3;
+    ev->lastTrunkPrec = prec;
+    {
+        Range r("nsg.planes");
+        NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, B, ev->numChannels, ev->cpad, prec, s));
+    }
+    {
+        Range r("nsg.trunk");
+        if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
+        NSG_HIP(nsg::launchTeamTrunk((const nsg::TeamLayer*)ev->teamLayers.p, ev->teamLayerCount, B,
+                                     (unsigned long long*)ev->teamCounters.p, ev->teamBases, ev->teamStatusDev, s));
+        for (int t = 0; t < B; ++t) ev->teamBases.v[t] += (unsigned long long)(ev->teamLayerCount - 1) * 32ull;
+        if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
+    }
+    void* x = (ev->blocks % 2 == 1) ? ev->act[2].p : ev->act[0].p; // the buffer rotation of the layer list
+    ev->trunkOut = x;
+    Range headsRange("nsg.heads");
+    NSG_HIP(nsg::launchHeads(x, ev->W->heads.w.p, (const float*)ev->W->heads.bias.p, (float*)ev->policy.p, ev->vfeat.p, B,
+                             ev->F, ev->headsCout, ev->vc, ev->fc1K, ev->W->heads.accScale, prec, s));
+    const size_t partStride = (size_t)ev->batchMax * ev->vh;
+    NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->W->fc1.w.p, (const float*)ev->W->fc1.bias.p, (float*)ev->hidden.p, B,
+                             ev->fc1K, ev->vh, partStride, ev->W->fc1.accScale, prec, s));
+    NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->W->fc1.bias.p, nsg::denseSplits(ev->fc1K, prec),
+                                partStride, (const float*)ev->W->fc2W.p, (const float*)ev->W->fc2B.p, (float*)ev->value.p,
+                                (float*)ev->draw.p, B, ev->vh, s));
+    return NSG_OK;
 }
 
 // One chain = the whole forward for boards [off, off + count) on stream `s`.
@@ -573,6 +633,27 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     }
     hipEvent_t* e = prof ? &ev->ev[ev->evUsed] : nullptr;
     if (prof) NSG_HIP(hipEventRecord(e[0], s));
+
+    // The smallest batches: every 3x3 layer in one persistent launch, a board per team of 32 workgroups
+    // (kernels/team_trunk.hip), when no tuning override asks for a particular per-layer plan and no other evaluator
+    // has a team launch in flight on this device.
+    ev->teamLast = false;
+    if (ev->teamLayerCount > 0 && ev->teamEnabled && B <= 8 && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 &&
+        ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && !ev->useTrunkKernel && acquireTeamToken(ev)) {
+        int rc = enqueueTeam(ev, B, s, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
+        if (rc) return rc;
+        ev->teamLast = true;
+        plan = nsg::ConvPlan{};
+        plan.nb = 1; plan.nfrag = 1; plan.nwaves = 8; plan.msplit = 2; plan.ksplit = 8; // 32 workgroups per board: 16 fragments x 2 row halves, K over 8 waves
+        ev->lastPlan = plan;
+        ev->lastChains = 1;
+        if (prof) {
+            NSG_HIP(hipEventRecord(e[3], s));
+            ev->evUsed += 4;
+            ev->pendingTrunkLaunchesPerFwd = 1;
+        }
+        return NSG_OK;
+    }
 
     // A batch with more tiles than CUs runs as two independent chains of half-batch
     // launches on separate streams: boards never interact, so chain A's layer l+1 may
@@ -758,6 +839,43 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
         const char* env = getenv("NSG_TRUNK_KERNEL");
         ev->useTrunkKernel = (env && env[0] == '1') ? 1 : 0;
     }
+    // team trunk layer list: the kF16x3 copy of the trunk (an MX evaluator keeps one for batches without an MX plan;
+    // a kF16x3 evaluator's own records), same buffer rotation
+    ev->teamLayerCount = 0;
+    const bool mxHere = nsg::isMx(prec);
+    if ((mxHere || prec == nsg::kF16x3) && N.blocks >= 1 && nsg::teamTrunkSupports(N.F, ev->cpad, 1) &&
+        (!mxHere || (N.stemX3.w.p && N.conv1X3.size() == (size_t)N.blocks))) {
+        const ConvLayer& stem = mxHere ? N.stemX3 : N.stem;
+        const std::vector<ConvLayer>& c1 = mxHere ? N.conv1X3 : N.conv1;
+        const std::vector<ConvLayer>& c2 = mxHere ? N.conv2X3 : N.conv2;
+        const int nl = 1 + 2 * N.blocks;
+        std::vector<nsg::TeamLayer> host((size_t)nl);
+        unsigned char* x = (unsigned char*)ev->act[0].p; unsigned char* y = (unsigned char*)ev->act[1].p;
+        unsigned char* z = (unsigned char*)ev->act[2].p;
+        host[0] = nsg::TeamLayer{(const unsigned char*)ev->planes.p, (const nsg::team_u32x4*)stem.w.p, (const float*)stem.bias.p,
+                                 nullptr, x, ev->cpad, N.F, 1, stem.accScale};
+        for (int k = 0; k < N.blocks; ++k) {
+            host[1 + 2 * k] = nsg::TeamLayer{x, (const nsg::team_u32x4*)c1[k].w.p, (const float*)c1[k].bias.p, nullptr, y,
+                                             N.F, N.F, 1, c1[k].accScale};
+            host[2 + 2 * k] = nsg::TeamLayer{y, (const nsg::team_u32x4*)c2[k].w.p, (const float*)c2[k].bias.p, x, z,
+                                             N.F, N.F, 1, c2[k].accScale};
+            unsigned char* t = x; x = z; z = t;
+        }
+        if ((rc = ev->teamLayers.alloc(host.size() * sizeof(nsg::TeamLayer), false))) return rc;
+        NSG_HIP(hipMemcpy(ev->teamLayers.p, host.data(), host.size() * sizeof(nsg::TeamLayer), hipMemcpyHostToDevice));
+        if (!ev->teamCounters.p) {
+            if ((rc = ev->teamCounters.alloc(8 * 64, true))) return rc;
+            ev->teamBases = nsg::TeamBases{};
+        }
+        if (!ev->teamStatusHost) {
+            NSG_HIP(hipHostMalloc((void**)&ev->teamStatusHost, 64, hipHostMallocMapped));
+            *ev->teamStatusHost = 0;
+            NSG_HIP(hipHostGetDevicePointer((void**)&ev->teamStatusDev, ev->teamStatusHost, 0));
+        }
+        ev->teamLayerCount = nl;
+        const char* env = getenv("NSG_TEAM_TRUNK");
+        ev->teamEnabled = (env && env[0] == '0') ? 0 : 1;
+    }
     NSG_HIP(hipDeviceSynchronize());
     ev->calibKey = -1; // a new network: re-measure the layer time for the chain stagger
     ev->calibPending = false;
@@ -796,7 +914,8 @@ static int checkTuningEnv() {
         {"NSG_SPLIT_BATCH", 0, 1, "full part + remainder batches"},
         {"NSG_SPLIT_BATCH_MAX", 0, 64, "largest batch (quarters of the CU count) that starts with a full chip of two-board tiles"}, {"NSG_ROCTX", 0, 1, "profiler markers"},
         {"NSG_SHARED_FORCE_COPY", 0, 1, "nsg_load_shared copies even on one device"},
-        {"NSG_SLAB_SPLIT", 0, 1, "slab-split two-board tiles at mid batches"}};
+        {"NSG_SLAB_SPLIT", 0, 1, "slab-split two-board tiles at mid batches"},
+        {"NSG_TEAM_TRUNK", 0, 1, "team trunk for batches of up to eight boards"}};
     for (const Var& v : vars) {
         const char* e = getenv(v.name);
         if (!e) continue;
@@ -875,6 +994,11 @@ int nsg_destroy(nsg_evaluator* ev) {
     if (ev->stream) {
         (void)hipStreamSynchronize(ev->stream);
     }
+    releaseTeamToken(ev);
+#ifdef TEAM_STAMPS
+    if (ev->teamLayerCount) nsg::teamTrunkDumpStamps();
+#endif
+    if (ev->teamStatusHost) (void)hipHostFree(ev->teamStatusHost);
     for (hipEvent_t e : ev->ev) (void)hipEventDestroy(e);
     for (auto cs : ev->chainStream)
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
@@ -1198,6 +1322,13 @@ int nsg_compute_gather_blocking(nsg_evaluator* ev, const void* features, size_t 
 int nsg_await(nsg_evaluator* ev) {
     if (!ev) return fail(NSG_E_INVALID, "null evaluator");
     NSG_HIP(hipStreamSynchronize(ev->stream)); // trt.cc:281-283
+    if (ev->teamStatusHost && *ev->teamStatusHost != 0) {
+        *ev->teamStatusHost = 0;
+        ev->teamEnabled = 0; // the per-layer kernels from here on
+        releaseTeamToken(ev);
+        return fail(NSG_E_HIP, "team trunk launch timed out waiting for its members (another persistent launch on this "
+                               "device?); outputs of this batch are undefined, later batches use the per-layer kernels");
+    }
     return NSG_OK;
 }
 

@@ -838,3 +838,68 @@ def test_slab_split_tiles(nsg, oracle, monkeypatch, channels, batch, ss, mx):
     p2, v2, d2 = ev.compute_blocking(bb[perm])  # (the tuning variables were read when `ev` was created)
     np.testing.assert_array_equal(p2, p[perm])
     np.testing.assert_array_equal(v2, v[perm])
+
+
+@pytest.mark.parametrize("precision", ["f16m6", "f16x3"])
+@pytest.mark.parametrize("blocks", [2, 5])
+def test_team_trunk_small_batches(nsg, oracle, monkeypatch, precision, blocks):
+    """Batches of up to eight boards: every 3x3 layer in ONE persistent launch, a board per team of 32 workgroups
+    that hand their 16-channel output slices to each other through agent-scope stores / loads and one counter per
+    team (kernels/team_trunk.hip), in the kF16x3 arithmetic.  Against the oracle, against the per-layer kernels of
+    the same arithmetic (NSG_TEAM_TRUNK=0: only the f32 summation order differs), bit-identical whatever else is in
+    the batch and from launch to launch (the team counters are never reset), and for every batch size 1..8."""
+    ev, blob = make(nsg, blocks, 256, 8, precision=precision, seed=300 + blocks)
+    net = oracle.net(blob)
+    bb = nsg.synth.random_batch(8, 86, seed=301, garbage=True)
+    ref = net.evaluate(bb)
+    outs = {}
+    for n in (8, 1, 3, 5, 2, 8):
+        p, v, d = ev.compute_blocking(bb[:n])
+        plan = ev.last_plan()
+        assert plan["trunk_precision"] == "f16x3" and plan["waves_per_group"] == 8 and plan["k_split"] == 8, plan
+        check((p, v, d), tuple(r[:n] for r in ref), 2e-4)
+        if n in outs:  # the same launch again, after others in between: the same bits
+            np.testing.assert_array_equal(p, outs[n][0])
+        outs[n] = (p, v, d)
+    for n in (1, 3, 5):  # a board's outputs do not depend on how many other boards share the launch
+        np.testing.assert_array_equal(outs[n][0], outs[8][0][:n])
+        np.testing.assert_array_equal(outs[n][1], outs[8][1][:n])
+    # a board alone in slot 0 == the same board in slot 6 of a full batch
+    p6, v6, _ = ev.compute_blocking(bb[6:7])
+    np.testing.assert_array_equal(p6[0], outs[8][0][6])
+    # device-resident forwards back to back (no await between them)
+    ev.upload_features(bb)
+    for _ in range(5):
+        ev.forward_resident(8)
+    pr, vr, dr = ev.download_outputs(8)
+    np.testing.assert_array_equal(pr, outs[8][0])
+    # the per-layer kernels of the same arithmetic
+    monkeypatch.setenv("NSG_TEAM_TRUNK", "0")
+    old, _ = make(nsg, blocks, 256, 8, precision="f16x3", seed=300 + blocks)
+    po, vo, do = old.compute_blocking(bb)
+    assert old.last_plan()["waves_per_group"] != 8
+    assert float(np.abs(po - outs[8][0]).max()) < 1e-4 and float(np.abs(vo - outs[8][1]).max()) < 1e-4
+    # nine boards: not a team batch
+    monkeypatch.delenv("NSG_TEAM_TRUNK")
+    big, _ = make(nsg, blocks, 256, 9, precision=precision, seed=300 + blocks)
+    big.compute_blocking(nsg.synth.random_batch(9, 86, seed=302))
+    assert big.last_plan()["waves_per_group"] != 8
+
+
+def test_team_trunk_two_evaluators_share_a_device(nsg, oracle):
+    """One team launch per device at a time: an evaluator whose neighbour has a team launch in flight runs that batch
+    on the per-layer kernels instead (never two persistent launches holding each other's CUs); results stay right."""
+    a, blob = make(nsg, 3, 256, 8, precision="f16m6", seed=310)
+    b = nsg.Evaluator(0, 8, 86, precision="f16m6")
+    b.load_memory(blob)
+    bb = nsg.synth.random_batch(8, 86, seed=311)
+    ref = oracle.net(blob).evaluate(bb)
+    pa = [np.empty((8, 2187), np.float32), np.empty(8, np.float32), np.empty(8, np.float32)]
+    pb = [np.empty((8, 2187), np.float32), np.empty(8, np.float32), np.empty(8, np.float32)]
+    for _ in range(20):
+        a.compute_nonblocking(bb, policy=pa[0], win=pa[1], draw=pa[2])
+        b.compute_nonblocking(bb, policy=pb[0], win=pb[1], draw=pb[2])
+        a.await_()
+        b.await_()
+        check(tuple(pa), ref, 2e-4)
+        check(tuple(pb), ref, 2e-4)
