@@ -127,7 +127,7 @@ hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
 // 32 workgroups that hand activations to each other through agent-scope stores / loads and one counter per team.
 // kF16x3 arithmetic, records and activation layout; 256 trunk channels.  `counters`: 8 x 8 u64 (one 64-byte line
 // per team), monotonic over the evaluator's lifetime: bases.v[t] = the value team t's counter holds before the
-// launch; the launch adds (nLayers - 1) * 32 to the counters of teams 0 .. boards-1.  `status`: a host-mapped int
+// launch; the launch adds (nLayers - 1) * teamMembers(boards) to the counters of teams 0 .. boards-1.  `status`: a host-mapped int
 // the kernel raises when a bounded spin runs out.
 typedef unsigned int team_u32x4 __attribute__((ext_vector_type(4)));
 struct TeamLayer {
@@ -141,6 +141,7 @@ struct TeamLayer {
 };
 struct TeamBases { unsigned long long v[8]; };
 bool teamTrunkSupports(int channels, int stemKdim, int boards);
+int teamMembers(int boards); // workgroups per board of a launch of `boards` boards: the launch adds (nLayers - 1) * that
 #ifdef TEAM_STAMPS
 void teamTrunkDumpStamps(); // diagnostic builds: per-phase cycles of one member, printed when an evaluator is destroyed
 #endif

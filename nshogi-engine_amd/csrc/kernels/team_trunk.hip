@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 namespace nsg {
 namespace {
@@ -41,7 +42,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
-constexpr int kWaves = 8, kThreads = kWaves * 64, kMembers = 32;
+constexpr int kWaves = 8, kThreads = kWaves * 64;
 constexpr int kEntries = 134;             // 24 + 110: one board with its halo (mfma_tile.h)
 // one 16-byte piece of every entry; a multiple of 256 B: the four lane groups of a fragment read (four planes, the
 // same entries) then fall on disjoint banks -- with 134 * 16 = 2144 B planes every read cost 12 LDS cycles instead of
@@ -95,12 +96,19 @@ __device__ __forceinline__ void splitPair(float a, float b, float floorV, unsign
 __device__ u64 gTeamStamps[32 * 8];
 #endif
 
+// FR = row fragments per member: 3 (a board = 16 weight fragments x 2 row halves = 32 members, up to eight boards) or
+// 1 (16 x 6 = 96 members per board, a single board -- the launch allows two --: a third of the MFMAs, fragment reads and tile rows per member,
+// and the epilogue of one fragment; the members of a board then sit on every XCD, which costs a hand-off nothing
+// measurable once the payload is stored sc1 -- it leaves the producer's L2 either way).
+template <int FR>
 __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* __restrict__ layers, int nLayers,
                                                                int boards, u64* counters, TeamBases bases, int* status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int team = blockIdx.x & 7, rank = blockIdx.x >> 3;
+    constexpr int kMembers = 16 * (6 / FR);
+    const int team = FR == 3 ? (int)(blockIdx.x & 7) : (int)(blockIdx.x / kMembers);
+    const int rank = FR == 3 ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x % kMembers);
     if (team >= boards || rank >= kMembers) return;
-    const int j = rank & 15, h = rank >> 4; // weight fragment (16 output channels), row half
+    const int j = rank & 15, h = rank >> 4; // weight fragment (16 output channels), row group (half or single fragment)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // = this wave's 32-channel chunk of K
     unsigned char* img = smem + wave * kImage;
@@ -110,10 +118,10 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
     // the image's halo entries stay zero for the whole launch: staging rewrites interior entries only
     for (int i = lane; i < kImage / 16; i += 64) reinterpret_cast<u32x4*>(img)[i] = u32x4{0u, 0u, 0u, 0u};
 
-    int abase[3]; // LDS read base of this lane's row in each of the member's three row fragments
+    int abase[FR]; // LDS read base of this lane's row in each of the member's row fragments
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
-        const int m = (h * 3 + f) * 16 + li;
+    for (int f = 0; f < FR; ++f) {
+        const int m = (h * FR + f) * 16 + li;
         abase[f] = ((m < 81 ? entryOf(m) : 11) - 11) * 16; // 11: every tap reads the zero entries
     }
     // staging: item k of a lane = piece lane / 8 of row k*8 + lane % 8 of this wave's chunk.  Eight consecutive
@@ -123,7 +131,9 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
     // first row half (fragments 0-2 = squares 0..47, + their neighbours below), 38..80 for the second (63 % of the board on
     // average: a handed-off tile arrives at ~70 GB/s per CU, MI355X_MICROARCH.md handoff-payload)
     const int stPiece = lane >> 3;
-    const int rowLo = h == 0 ? 0 : 38, rowHi = h == 0 ? 57 : 80;
+    // (rows of the member's fragments -1 / +1 board row: 16*first - 10 .. 16*last + 25, clipped to the board)
+    const int rowLo = (h * FR) * 16 - 10 > 0 ? (h * FR) * 16 - 10 : 0;
+    const int rowHi = (h * FR + FR) * 16 + 9 < 80 ? (h * FR + FR) * 16 + 9 : 80;
     int srcRow[kItems], dstOff[kItems];
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
@@ -134,9 +144,9 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
     // K parts: after its MFMAs a wave parks its three accumulator fragments in INTERIOR entries of its own image (the
     // halo entries must stay zero; the next layer's staging rewrites every interior entry): 16-byte slot f*64 + lane
     // -> piece slot / 32, square slot % 32
-    int redOff[3];
+    int redOff[FR];
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
+    for (int f = 0; f < FR; ++f) {
         const int slot = f * 64 + lane;
         redOff[f] = (slot >> 5) * kPlane + entryOf(slot & 31) * 16;
     }
@@ -191,11 +201,11 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         // ---- this wave's chunk of the board -> its LDS image (agent-scope loads: never the L1 of this CU)
         TEAM_STAMP(1)
         // (waves 0..2 also request their residual rows now: one round trip, hidden behind the tile and the MFMAs)
-        const int mOut = (h * 3 + (wave < 3 ? wave : 0)) * 16 + li;
+        const int mOut = (h * FR + (wave < FR ? wave : 0)) * 16 + li;
         const size_t rowOff = ((size_t)team * 81 + (mOut < 81 ? mOut : 0)) * outRow + outOff;
         u64 resHi = 0, resLo = 0;
         f32x4 biasV = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (wave < 3) {
+        if (wave < FR) {
             biasV = *asGlobal<f32x4>(L.bias + ch0);
             if (L.res && mOut < 81) {
                 resHi = loadAgent(L.res + rowOff);
@@ -217,15 +227,17 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         }
         TEAM_STAMP(2)
         // (a wave reads only its own image: its own LDS writes are ordered before its reads, no barrier)
-        f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[FR];
+#pragma unroll
+        for (int f = 0; f < FR; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (wave < nkc) {
             // row fragments one tap ahead of their MFMAs (left to itself the compiler reads, waits, multiplies: the
             // layer's 54 LDS round trips in series were 5.0k of its 15.6k cycles)
-            f16x8 xh[2][3], xl[2][3];
+            f16x8 xh[2][FR], xl[2][FR];
             auto readTap = [&](int t, int buf) {
                 const int tapOff = ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16;
 #pragma unroll
-                for (int f = 0; f < 3; ++f) {
+                for (int f = 0; f < FR; ++f) {
                     xh[buf][f] = *reinterpret_cast<const f16x8*>(img + g * kPlane + abase[f] + tapOff);
                     xl[buf][f] = *reinterpret_cast<const f16x8*>(img + (4 + g) * kPlane + abase[f] + tapOff);
                 }
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                 if (t + 1 < 9) readTap(t + 1, (t + 1) & 1);
                 const f16x8 whi = __builtin_bit_cast(f16x8, w[t][0]), wlo = __builtin_bit_cast(f16x8, w[t][1]);
 #pragma unroll
-                for (int f = 0; f < 3; ++f) {
+                for (int f = 0; f < FR; ++f) {
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, xh[t & 1][f], acc[f], 0, 0, 0);
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh[t & 1][f], acc[f], 0, 0, 0);
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, xl[t & 1][f], acc[f], 0, 0, 0);
@@ -247,12 +259,11 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         TEAM_STAMP(3)
         // ---- add the K parts (fixed order: deterministic), waves 0..2 finish one row fragment each
 #pragma unroll
-        for (int f = 0; f < 3; ++f) *reinterpret_cast<f32x4*>(img + redOff[f]) = acc[f];
+        for (int f = 0; f < FR; ++f) *reinterpret_cast<f32x4*>(img + redOff[f]) = acc[f];
         __syncthreads();
         TEAM_STAMP(4)
-        if (wave < 3) {
-            const int f = wave;
-            const int ro = f == 0 ? redOff[0] : (f == 1 ? redOff[1] : redOff[2]);
+        if (wave < FR) {
+            const int ro = redOff[FR == 1 ? 0 : (wave < FR ? wave : 0)];
             f32x4 sum = *reinterpret_cast<const f32x4*>(smem + ro);
 #pragma unroll
             for (int p = 1; p < kWaves; ++p) sum += *reinterpret_cast<const f32x4*>(smem + p * kImage + ro);
@@ -293,6 +304,15 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 
 } // namespace
 
+// Members per board: 96 (one row fragment each) for a single board, 32 (three each) for two to eight (measured,
+// profiles/r03/g_team_trunk_members.txt: one board 4.76k against 3.34k evals/s, two boards 6.31k against 6.71k).
+// NSG_TEAM_MEMBERS = 32 | 96 overrides (96: one or two boards only).
+int teamMembers(int boards) {
+    static const int force = [] { const char* e = getenv("NSG_TEAM_MEMBERS"); return e ? atoi(e) : 0; }();
+    if (force == 32 || force == 96) return (force == 96 && boards > 2) ? 32 : force;
+    return boards == 1 ? 96 : 32;
+}
+
 bool teamTrunkSupports(int channels, int stemKdim, int boards) {
     return channels == 256 && stemKdim % 32 == 0 && stemKdim <= 256 && boards >= 1 && boards <= 8;
 }
@@ -316,12 +336,17 @@ hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, 
     if (nLayers < 1 || boards < 1 || boards > 8) return hipErrorInvalidValue;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)teamTrunkKernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        hipError_t e = hipFuncSetAttribute((const void*)teamTrunkKernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)teamTrunkKernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(teamTrunkKernel, dim3(8 * kMembers), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
-                       counters, bases, status);
+    if (teamMembers(boards) == 96)
+        hipLaunchKernelGGL(teamTrunkKernel<1>, dim3(boards * 96), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
+                           counters, bases, status);
+    else
+        hipLaunchKernelGGL(teamTrunkKernel<3>, dim3(8 * 32), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
+                           counters, bases, status);
     return hipGetLastError();
 }
 

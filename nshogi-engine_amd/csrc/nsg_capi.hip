@@ -464,7 +464,8 @@ int enqueueTeam(nsg_evaluator* ev, int B, hipStream_t s, hipEvent_t trunkBegin, 
         if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
         NSG_HIP(nsg::launchTeamTrunk((const nsg::TeamLayer*)ev->teamLayers.p, ev->teamLayerCount, B,
                                      (unsigned long long*)ev->teamCounters.p, ev->teamBases, ev->teamStatusDev, s));
-        for (int t = 0; t < B; ++t) ev->teamBases.v[t] += (unsigned long long)(ev->teamLayerCount - 1) * 32ull;
+        for (int t = 0; t < B; ++t)
+            ev->teamBases.v[t] += (unsigned long long)(ev->teamLayerCount - 1) * (unsigned long long)nsg::teamMembers(B);
         if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
     }
     void* x = (ev->blocks % 2 == 1) ? ev->act[2].p : ev->act[0].p; // the buffer rotation of the layer list
@@ -644,7 +645,8 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         if (rc) return rc;
         ev->teamLast = true;
         plan = nsg::ConvPlan{};
-        plan.nb = 1; plan.nfrag = 1; plan.nwaves = 8; plan.msplit = 2; plan.ksplit = 8; // 32 workgroups per board: 16 fragments x 2 row halves, K over 8 waves
+        plan.nb = 1; plan.nfrag = 1; plan.nwaves = 8; plan.ksplit = 8; // 16 weight fragments x 2 or 6 row groups per board, K over 8 waves
+        plan.msplit = nsg::teamMembers(B) / 16;
         ev->lastPlan = plan;
         ev->lastChains = 1;
         if (prof) {
