@@ -198,6 +198,8 @@ def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch, ksplit, 
     if (ksplit == 2 and not (wg <= cus < 2 * wg)) or (ksplit in (3, 4) and batch * ksplit > cus):
         pytest.skip("batch range of this plan depends on the CU count")
     bmax = max(batch, 2)
+    if batch <= 8:  # (round 3: up to eight boards run the team trunk by default -- test_team_trunk_small_batches;
+        monkeypatch.setenv("NSG_TEAM_TRUNK", "0")  # these per-layer plans are what it falls back to)
     ev, blob = make(nsg, 3, channels, bmax, precision=mx, seed=63)
     bb = nsg.synth.random_batch(batch, 86, seed=64, garbage=True)
     p, v, d = ev.compute_blocking(bb)
