@@ -125,7 +125,7 @@ hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
 
 // Team trunk (team_trunk.hip): every 3x3 layer of up to eight boards in ONE persistent launch, a board per team of
 // 32 workgroups that hand activations to each other through agent-scope stores / loads and one counter per team.
-// kF16x3 arithmetic, records and activation layout; 256 trunk channels.  `counters`: 8 x 8 u64 (one 64-byte line
+// kF16x3 arithmetic, records and activation layout; 256 trunk channels.  `counters`: kTeamMaxBoards x 8 u64 (one 64-byte line
 // per team), monotonic over the evaluator's lifetime: bases.v[t] = the value team t's counter holds before the
 // launch; the launch adds (nLayers - 1) * teamMembers(boards) to the counters of teams 0 .. boards-1.  `status`: a host-mapped int
 // the kernel raises when a bounded spin runs out.
@@ -139,7 +139,8 @@ struct TeamLayer {
     int kdim, cout, relu;
     float accScale;
 };
-struct TeamBases { unsigned long long v[8]; };
+constexpr int kTeamMaxBoards = 16;
+struct TeamBases { unsigned long long v[kTeamMaxBoards]; };
 bool teamTrunkSupports(int channels, int stemKdim, int boards);
 int teamMembers(int boards); // workgroups per board of a launch of `boards` boards: the launch adds (nLayers - 1) * that
 #ifdef TEAM_STAMPS

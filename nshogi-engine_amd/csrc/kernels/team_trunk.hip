@@ -105,9 +105,10 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                                                                int boards, u64* counters, TeamBases bases, int* status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kMembers = 16 * (6 / FR);
+    constexpr int kSub = FR > 3 ? 3 : FR, kSubs = FR / kSub; // row fragments per fragment-read step, steps per tap
     const int team = FR == 3 ? (int)(blockIdx.x & 7) : (int)(blockIdx.x / kMembers);
     const int rank = FR == 3 ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x % kMembers);
-    if (team >= boards || rank >= kMembers) return;
+    if (team >= boards || rank >= kMembers || team >= kTeamMaxBoards) return;
     const int j = rank & 15, h = rank >> 4; // weight fragment (16 output channels), row group (half or single fragment)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // = this wave's 32-channel chunk of K
@@ -142,13 +143,13 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         dstOff[k] = stPiece * kPlane + entryOf(row < 81 ? row : 0) * 16;
     }
     // K parts: after its MFMAs a wave parks its three accumulator fragments in INTERIOR entries of its own image (the
-    // halo entries must stay zero; the next layer's staging rewrites every interior entry): 16-byte slot f*64 + lane
-    // -> piece slot / 32, square slot % 32
+    // halo entries must stay zero; the next layer's staging rewrites every interior entry it reads): 16-byte slot
+    // f*64 + lane -> piece slot / (8 FR), square slot % (8 FR) -- squares inside the rows this member stages
     int redOff[FR];
 #pragma unroll
     for (int f = 0; f < FR; ++f) {
-        const int slot = f * 64 + lane;
-        redOff[f] = (slot >> 5) * kPlane + entryOf(slot & 31) * 16;
+        const int slot = f * 64 + lane; // FR * 64 slots over the eight pieces: 8 * FR squares of each
+        redOff[f] = (slot / (8 * FR)) * kPlane + entryOf(slot % (8 * FR)) * 16;
     }
     // output: lane (li, g) of fragment f holds channels ch0 .. ch0+3 of row (h*3+f)*16 + li
     const int ch0 = (j >> 2) * 64 + g * 16 + (j & 3) * 4;
@@ -233,27 +234,30 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         if (wave < nkc) {
             // row fragments one tap ahead of their MFMAs (left to itself the compiler reads, waits, multiplies: the
             // layer's 54 LDS round trips in series were 5.0k of its 15.6k cycles)
-            f16x8 xh[2][FR], xl[2][FR];
-            auto readTap = [&](int t, int buf) {
+            f16x8 xh[2][kSub], xl[2][kSub];
+            auto readStep = [&](int st_, int buf) { // step = (tap, group of kSub fragments)
+                const int t = st_ / kSubs, sub = st_ % kSubs;
                 const int tapOff = ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16;
 #pragma unroll
-                for (int f = 0; f < FR; ++f) {
-                    xh[buf][f] = *reinterpret_cast<const f16x8*>(img + g * kPlane + abase[f] + tapOff);
-                    xl[buf][f] = *reinterpret_cast<const f16x8*>(img + (4 + g) * kPlane + abase[f] + tapOff);
+                for (int f = 0; f < kSub; ++f) {
+                    xh[buf][f] = *reinterpret_cast<const f16x8*>(img + g * kPlane + abase[sub * kSub + f] + tapOff);
+                    xl[buf][f] = *reinterpret_cast<const f16x8*>(img + (4 + g) * kPlane + abase[sub * kSub + f] + tapOff);
                 }
             };
-            readTap(0, 0);
+            readStep(0, 0);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (t + 1 < 9) readTap(t + 1, (t + 1) & 1);
+            for (int st_ = 0; st_ < 9 * kSubs; ++st_) {
+                if (st_ + 1 < 9 * kSubs) readStep(st_ + 1, (st_ + 1) & 1);
+                const int t = st_ / kSubs, sub = st_ % kSubs;
                 const f16x8 whi = __builtin_bit_cast(f16x8, w[t][0]), wlo = __builtin_bit_cast(f16x8, w[t][1]);
 #pragma unroll
-                for (int f = 0; f < FR; ++f) {
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, xh[t & 1][f], acc[f], 0, 0, 0);
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh[t & 1][f], acc[f], 0, 0, 0);
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, xl[t & 1][f], acc[f], 0, 0, 0);
+                for (int f = 0; f < kSub; ++f) {
+                    f32x4& a = acc[sub * kSub + f];
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, xh[st_ & 1][f], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh[st_ & 1][f], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, xl[st_ & 1][f], a, 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0); // a tap's reads stay in front of the tap before's MFMAs
+                __builtin_amdgcn_sched_barrier(0); // a step's reads stay in front of the step before's MFMAs
             }
         }
         TEAM_STAMP(3)
@@ -307,14 +311,17 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 // Members per board: 96 (one row fragment each) for a single board, 32 (three each) for two to eight (measured,
 // profiles/r03/g_team_trunk_members.txt: one board 4.76k against 3.34k evals/s, two boards 6.31k against 6.71k).
 // NSG_TEAM_MEMBERS = 32 | 96 overrides (96: one or two boards only).
+// Nine to sixteen boards: 16 members per board, one weight fragment x the whole board each.
 int teamMembers(int boards) {
     static const int force = [] { const char* e = getenv("NSG_TEAM_MEMBERS"); return e ? atoi(e) : 0; }();
+    if (boards > 8) return 16;
+    if (force == 16) return 16;
     if (force == 32 || force == 96) return (force == 96 && boards > 2) ? 32 : force;
     return boards == 1 ? 96 : 32;
 }
 
 bool teamTrunkSupports(int channels, int stemKdim, int boards) {
-    return channels == 256 && stemKdim % 32 == 0 && stemKdim <= 256 && boards >= 1 && boards <= 8;
+    return channels == 256 && stemKdim % 32 == 0 && stemKdim <= 256 && boards >= 1 && boards <= kTeamMaxBoards;
 }
 
 #ifdef TEAM_STAMPS
@@ -333,16 +340,20 @@ void teamTrunkDumpStamps() {
 
 hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, unsigned long long* counters,
                            const TeamBases& bases, int* status, hipStream_t stream) {
-    if (nLayers < 1 || boards < 1 || boards > 8) return hipErrorInvalidValue;
+    if (nLayers < 1 || boards < 1 || boards > kTeamMaxBoards) return hipErrorInvalidValue;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)teamTrunkKernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)teamTrunkKernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)teamTrunkKernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return e;
         attr = true;
     }
     if (teamMembers(boards) == 96)
         hipLaunchKernelGGL(teamTrunkKernel<1>, dim3(boards * 96), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
+                           counters, bases, status);
+    else if (teamMembers(boards) == 16)
+        hipLaunchKernelGGL(teamTrunkKernel<6>, dim3(boards * 16), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
                            counters, bases, status);
     else
         hipLaunchKernelGGL(teamTrunkKernel<3>, dim3(8 * 32), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,

@@ -639,7 +639,9 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // (kernels/team_trunk.hip), when no tuning override asks for a particular per-layer plan and no other evaluator
     // has a team launch in flight on this device.
     ev->teamLast = false;
-    if (ev->teamLayerCount > 0 && ev->teamEnabled && B <= 8 && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 &&
+    static const int teamMax = [] { const char* e = getenv("NSG_TEAM_MAX_BATCH"); const int v = e ? atoi(e) : nsg::kTeamMaxBoards;
+                                    return v < 0 ? 0 : (v > nsg::kTeamMaxBoards ? nsg::kTeamMaxBoards : v); }();
+    if (ev->teamLayerCount > 0 && ev->teamEnabled && B <= teamMax && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 &&
         ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && !ev->useTrunkKernel && acquireTeamToken(ev)) {
         int rc = enqueueTeam(ev, B, s, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
         if (rc) return rc;
@@ -866,7 +868,7 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
         if ((rc = ev->teamLayers.alloc(host.size() * sizeof(nsg::TeamLayer), false))) return rc;
         NSG_HIP(hipMemcpy(ev->teamLayers.p, host.data(), host.size() * sizeof(nsg::TeamLayer), hipMemcpyHostToDevice));
         if (!ev->teamCounters.p) {
-            if ((rc = ev->teamCounters.alloc(8 * 64, true))) return rc;
+            if ((rc = ev->teamCounters.alloc(nsg::kTeamMaxBoards * 64, true))) return rc;
             ev->teamBases = nsg::TeamBases{};
         }
         if (!ev->teamStatusHost) {
@@ -917,7 +919,9 @@ static int checkTuningEnv() {
         {"NSG_SPLIT_BATCH_MAX", 0, 64, "largest batch (quarters of the CU count) that starts with a full chip of two-board tiles"}, {"NSG_ROCTX", 0, 1, "profiler markers"},
         {"NSG_SHARED_FORCE_COPY", 0, 1, "nsg_load_shared copies even on one device"},
         {"NSG_SLAB_SPLIT", 0, 1, "slab-split two-board tiles at mid batches"},
-        {"NSG_TEAM_TRUNK", 0, 1, "team trunk for batches of up to eight boards"}};
+        {"NSG_TEAM_TRUNK", 0, 1, "team trunk for the smallest batches"},
+        {"NSG_TEAM_MAX_BATCH", 0, 16, "largest batch that runs the team trunk"},
+        {"NSG_TEAM_MEMBERS", 16, 96, "workgroups per board of the team trunk (16, 32 or 96)"}};
     for (const Var& v : vars) {
         const char* e = getenv(v.name);
         if (!e) continue;

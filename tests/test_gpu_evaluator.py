@@ -849,7 +849,8 @@ def test_team_trunk_small_batches(nsg, oracle, monkeypatch, precision, blocks):
     that hand their 16-channel output slices to each other through agent-scope stores / loads and one counter per
     team (kernels/team_trunk.hip), in the kF16x3 arithmetic.  Against the oracle, against the per-layer kernels of
     the same arithmetic (NSG_TEAM_TRUNK=0: only the f32 summation order differs), bit-identical whatever else is in
-    the batch and from launch to launch (the team counters are never reset), and for every batch size 1..8."""
+    the batch and from launch to launch (the team counters are never reset), for batch sizes 1..8 (96 or 32
+    workgroups per board) and 9..16 (16 per board)."""
     ev, blob = make(nsg, blocks, 256, 8, precision=precision, seed=300 + blocks)
     net = oracle.net(blob)
     bb = nsg.synth.random_batch(8, 86, seed=301, garbage=True)
@@ -881,10 +882,20 @@ def test_team_trunk_small_batches(nsg, oracle, monkeypatch, precision, blocks):
     po, vo, do = old.compute_blocking(bb)
     assert old.last_plan()["waves_per_group"] != 8
     assert float(np.abs(po - outs[8][0]).max()) < 1e-4 and float(np.abs(vo - outs[8][1]).max()) < 1e-4
-    # nine boards: not a team batch
+    # nine to sixteen boards: 16 workgroups per board, the whole board each; seventeen: not a team batch
     monkeypatch.delenv("NSG_TEAM_TRUNK")
-    big, _ = make(nsg, blocks, 256, 9, precision=precision, seed=300 + blocks)
-    big.compute_blocking(nsg.synth.random_batch(9, 86, seed=302))
+    big, _ = make(nsg, blocks, 256, 17, precision=precision, seed=300 + blocks)
+    bb17 = nsg.synth.random_batch(17, 86, seed=302, garbage=True)
+    ref17 = net.evaluate(bb17)
+    p16, v16, d16 = big.compute_blocking(bb17[:16])
+    plan = big.last_plan()
+    assert plan["waves_per_group"] == 8 and plan["k_split"] == 8 and plan["row_split"] == 1, plan
+    check((p16, v16, d16), tuple(r[:16] for r in ref17), 2e-4)
+    p9, v9, d9 = big.compute_blocking(bb17[:9])
+    np.testing.assert_array_equal(p9, p16[:9])
+    p8, _, _ = big.compute_blocking(bb17[:8])  # 32 workgroups per board: another summation order of the K parts? no: the same
+    assert float(np.abs(p8 - p16[:8]).max()) < 1e-4
+    big.compute_blocking(bb17)
     assert big.last_plan()["waves_per_group"] != 8
 
 
