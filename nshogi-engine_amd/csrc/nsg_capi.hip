@@ -434,15 +434,18 @@ __global__ void delayKernel(unsigned long long ticks) {
 }
 
 // Two team launches on one device could each hold CUs that the other's not-yet-scheduled members need.  One token
-// per device: an evaluator may launch a team trunk if it holds the token already (its launches are ordered on its
-// own stream) or if the holder's stream is idle; otherwise this forward runs the per-layer kernels.
+// per device: an evaluator launches a team trunk if it holds the token already (its launches are ordered on its own
+// stream); otherwise it first waits, on the host, until the holder's stream has drained (at most one small-batch
+// forward) and takes the token.  Waiting -- not falling back to the per-layer kernels -- keeps the arithmetic of a
+// batch independent of timing: a self-play engine's two executors then produce the same bits in every run.
+// (The mutex is held across the wait: the holder cannot be destroyed under it, nsg_destroy releases the token first.)
 std::mutex gTeamMutex;
 nsg_evaluator* gTeamOwner[64] = {};
 bool acquireTeamToken(nsg_evaluator* ev) {
     std::lock_guard<std::mutex> lock(gTeamMutex);
     nsg_evaluator*& owner = gTeamOwner[ev->gpu & 63];
     if (owner == ev) return true;
-    if (owner != nullptr && hipStreamQuery(owner->stream) != hipSuccess) return false;
+    if (owner != nullptr && hipStreamSynchronize(owner->stream) != hipSuccess) return false;
     owner = ev;
     return true;
 }
