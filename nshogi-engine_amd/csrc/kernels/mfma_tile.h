@@ -632,7 +632,7 @@ _Pragma("unroll") \
         using Q = M8Seq<G::kTaps>;
         using OS = OwnSeq<SS, PART>; // the slabs of a pair this wave runs, in its own order (SS = 1: all 27)
         static_assert(G::kTaps == 9, "3x3 taps");
-        constexpr int kWin = 9, kD = 7;
+        constexpr int kWin = 9, kD = 7; // (five or eight steps of lead: +-0.5 %, profiles/r03/README.md)
         using ST = StepSeq<OS, kMFw, kPerm, kWin>;
         constexpr int kReal = ST::kReal;   // (own slab, fragment) steps that issue MFMAs
         constexpr int kSteps = ST::kSteps; // ... padded to a multiple of the window: a step's slot is the same in every pair
