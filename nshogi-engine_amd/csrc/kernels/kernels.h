@@ -123,12 +123,10 @@ bool canRunTrunk(int cout, const ConvPlan& plan);
 hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
                        const ConvPlan& plan, hipStream_t stream);
 
-// Team trunk (team_trunk.hip): every 3x3 layer of up to eight boards in ONE persistent launch, a board per team of
-// 32 workgroups that hand activations to each other through agent-scope stores / loads and one counter per team.
-// kF16x3 arithmetic, records and activation layout; 256 trunk channels.  `counters`: kTeamMaxBoards x 8 u64 (one 64-byte line
-// per team), monotonic over the evaluator's lifetime: bases.v[t] = the value team t's counter holds before the
-// launch; the launch adds (nLayers - 1) * teamMembers(boards) to the counters of teams 0 .. boards-1.  `status`: a host-mapped int
-// the kernel raises when a bounded spin runs out.
+// Team trunk (team_trunk.hip): every 3x3 layer of up to sixteen boards in ONE persistent launch, a board per team of
+// 16 / 32 / 96 workgroups that hand activations to each other through agent-scope stores / loads; the payload is
+// its own flag (TeamHandoff).  kF16x3 arithmetic, records and activation layout; 256 trunk channels.  `status`: a
+// host-mapped int the kernel raises when a bounded spin runs out.
 typedef unsigned int team_u32x4 __attribute__((ext_vector_type(4)));
 struct TeamLayer {
     const unsigned char* x;   // [boards][81][kdim] kF16x3
@@ -140,14 +138,25 @@ struct TeamLayer {
     float accScale;
 };
 constexpr int kTeamMaxBoards = 16;
-struct TeamBases { unsigned long long v[kTeamMaxBoards]; };
+// Hand-off buffers of a launch: `set` = four images of imageStride bytes (>= boards x 81 x 1024); layer l <
+// nLayers - 1 writes image l % 4 of boards 0 .. boards-1.  When the launch starts every byte of those boards is 0xff;
+// when it ends that holds again but for image (nLayers - 2) % 4.  `other` = the set the launch before this one used:
+// the first cleanBoards boards of ITS image (nLayers - 2) % 4 are rewritten with 0xff.  Layer 0 reads TeamLayer::x,
+// the last layer writes TeamLayer::y; TeamLayer::res != null means "the output of the layer two before" (a residual
+// block's input).  nLayers >= 3.
+struct TeamHandoff {
+    unsigned char* set;
+    unsigned char* other;
+    size_t imageStride;
+    int cleanBoards;
+};
 bool teamTrunkSupports(int channels, int stemKdim, int boards);
-int teamMembers(int boards); // workgroups per board of a launch of `boards` boards: the launch adds (nLayers - 1) * that
+int teamMembers(int boards); // workgroups per board of a launch of `boards` boards
 #ifdef TEAM_STAMPS
 void teamTrunkDumpStamps(); // diagnostic builds: per-phase cycles of one member, printed when an evaluator is destroyed
 #endif
-hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, unsigned long long* counters,
-                           const TeamBases& bases, int* status, hipStream_t stream);
+hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, const TeamHandoff& handoff, int* status,
+                           hipStream_t stream);
 
 // Policy 1x1 conv (27 ch, +bias, raw logits -> policy[b][c*81+sq] f32) and
 // value-feature 1x1 conv (VC ch, folded-BN bias, ReLU -> vfeat[b*vfeatStride + sq*VC+c] T)

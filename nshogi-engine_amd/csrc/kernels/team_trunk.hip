@@ -13,16 +13,30 @@
 // image: no workgroup barrier), runs 81 MFMAs per wave, adds the eight K parts through LDS, finishes three row
 // fragments (bias, residual, ReLU, f16 hi/lo split) and hands its 3 KB of output to the team.
 //
-// Hand-off (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", measured form
-// of its table's first row): every output byte is stored with an agent-scope relaxed atomic store (sc1,
-// write-through), every storing wave drains its stores (vmcnt(0)), the workgroup meets at a barrier, ONE lane adds
-// 1 to the team's counter (agent-scope atomic); a consumer's wave 0 polls that counter with agent-scope relaxed
-// loads (sc1), the workgroup meets at a barrier, and every load of handed-off bytes is an agent-scope relaxed
-// atomic load (sc1, never L1).  Counters are 64-bit and monotonic over the evaluator's lifetime (no reset between
-// launches).  Every spin is bounded: a member that waits longer than ~1 s raises `status` (host-mapped) and the
-// launch unwinds; the host turns that into an error at await.  Two team launches must not share a device at the
-// same time (each would hold CUs the other's unscheduled members need): nsg_capi.hip keeps one token per device
-// and a second evaluator falls back to the per-layer kernels.
+// Hand-off: the payload is its own flag.  The layers but the last write into four rotating buffers (`TeamHandoff::
+// set`, [boards][81][256] kF16x3 images; layer l writes image l % 4) that hold the SENTINEL -- all bits set -- where
+// nothing has been handed over yet.  A producer stores its output with 8-byte agent-scope relaxed atomic stores
+// (sc1, write-through; four channels' hi halves or lo halves each: single-copy atomic) and does not wait for them.
+// A consumer requests its input tile with 16-byte agent-scope loads (sc1, never this CU's L1), checks one word of
+// each 8-byte half against the sentinel and requests the pieces that were not there yet again, until all are.  No
+// value a layer stores contains the sentinel: a stored half is an f16 of a number clamped to +-65000, or of the
+// difference between such a number and its f16 rounding; 0xffff is a NaN.  A layer therefore costs ONE one-way trip of
+// its payload on the critical path (the counter protocol this replaces paid for a store drain, an atomic add, a
+// poll and then the tile's round trip: profiles/r03/README.md).
+//   Reuse of an image.  Write C(n, l) for the moment ALL EIGHT waves of member n have their input of layer l (the
+// workgroup barrier behind the MFMAs; the input includes every neighbour's -- every member's whose rows n reads,
+// which are the members that read n's -- output of layer l - 1) and F(n, l) > C(n, l) for its output stores of layer l.  At C(n, l) member n puts the sentinel back over its own output of layer l - 2 (the residual
+// of layer l, requested before the tile, has arrived by then): every neighbour m has stored layer l - 1, so has read
+// layer l - 2.  The waves that store the sentinel wait for all their memory operations (vmcnt(0)) at C(n, l + 1),
+// before F(n, l + 1).  A member m that looks at that place again -- for layer l + 2's output, after F(m, l + 2) >
+// C(m, l + 2) > F(n, l + 1) -- finds the sentinel or the new value, never the old one; and n overwrites layer l - 2's
+// image with layer l + 2's after C(n, l + 2) > F(m, l + 1) > C(m, l + 1): after every neighbour has read layer l.
+//   Across launches.  The last layer but one's image (nLayers - 2) is still being read when the launch ends: it is
+// left as it is.  Two sets alternate between launches and a launch restores the sentinel in that one image of the
+// OTHER set (`cleanBoards` boards of it; the kernel boundary orders that against the set's next use).
+//   Every spin is bounded: a member that waits longer than ~1 s raises `status` (host-mapped) and the launch unwinds;
+// the host turns that into an error at await.  Two team launches must not share a device at the same time (each
+// would hold CUs the other's unscheduled members need): nsg_capi.hip keeps one token per device.
 //
 // Arithmetic: kF16x3 (split f16 hi/lo, three f16 MFMAs per MAC, f32 accumulate) on the kF16x3 records and
 // activation layout the evaluator keeps for batches without an MX plan -- a channel subset can be written
@@ -49,9 +63,9 @@ constexpr int kEntries = 134;             // 24 + 110: one board with its halo (
 // 4 and the eight waves' 54 reads per layer, not their 81 MFMAs, set the layer's compute time (5.0k of 15.6k cycles)
 constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
 constexpr int kImage = 8 * kPlane;        // a wave's chunk: pieces 0-3 f16 hi, 4-7 f16 lo
-constexpr int kLds = kWaves * kImage;     // 147 456 B: the K parts' accumulators alias the images' interior entries
+constexpr int kFlagOff = kWaves * kImage; // one int behind the images: raised by a wave whose bounded wait ran out
+constexpr int kLds = kFlagOff + 16;       // 147 472 B: the K parts' accumulators alias the images' interior entries
 static_assert(kLds <= 160 * 1024, "LDS");
-constexpr int kItems = (81 * 8 + 63) / 64; // 16-byte items of a wave's chunk of the board: 81 rows x 128 B
 
 // Pointers read out of the layer list are generic to the compiler (flat_ instructions); every one of them is global
 // memory, and the hand-off form above is measured for global_ sc1 accesses only: cast before use.
@@ -70,14 +84,24 @@ __device__ __forceinline__ u64 loadAgent(const void* p) { // global_load_dwordx2
 __device__ __forceinline__ void storeAgent(void* p, u64 v) { // global_store_dwordx2 ... sc1
     __hip_atomic_store(asGlobal<u64>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// 16-byte sc1 load (there is no 16-byte atomic builtin).  The compiler does not count this load in vmcnt: the caller
-// waits with waitLoads() before touching the result (its own waits only ever over-wait: vmcnt retires in order).
-__device__ __forceinline__ u32x4 loadAgent16(const void* p) {
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(asGlobal<u32x4>(p)) : "memory");
-    return v;
+// 16-byte agent-scope accesses (there is no 16-byte atomic builtin): raw buffer loads / stores with the sc1 bit
+// (buffer_load_dwordx4 ... offen sc1).  Compiler-visible on purpose: a first version issued global_load_dwordx4 sc1
+// from an asm statement and waited in another, and the scheduler moved register-only readers of the loaded values (a
+// v_max3 of a piece's words) in front of the wait -- nothing orders an asm's outputs against a later asm.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t bufferOf(const void* p) { // byte-addressed, no bounds to speak of
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00027000);
 }
-__device__ __forceinline__ void waitLoads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ u32x4 loadAgent16(rsrc_t r, int byteOff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byteOff, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ void storeAgent16(rsrc_t r, int byteOff, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byteOff, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) {
+    const unsigned ab = a > b ? a : b;
+    return ab > c ? ab : c; // v_max3_u32
+}
 __device__ __forceinline__ int entryOf(int m) { // LDS entry of board row m (mfma_tile.h: 24 + (y+1)*10 + x)
     const int y = m / 9, x = m - y * 9;
     return 24 + (y + 1) * 10 + x;
@@ -102,7 +126,7 @@ __device__ u64 gTeamStamps[32 * 8];
 // measurable once the payload is stored sc1 -- it leaves the producer's L2 either way).
 template <int FR>
 __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* __restrict__ layers, int nLayers,
-                                                               int boards, u64* counters, TeamBases bases, int* status) {
+                                                               int boards, TeamHandoff ho, int* status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kMembers = 16 * (6 / FR);
     constexpr int kSub = FR > 3 ? 3 : FR, kSubs = FR / kSub; // row fragments per fragment-read step, steps per tap
@@ -113,9 +137,10 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // = this wave's 32-channel chunk of K
     unsigned char* img = smem + wave * kImage;
-    u64* ctr = counters + team * 8; // one 64-byte line per team
-    const u64 base = bases.v[team];  // the counter's value when this launch's first layer starts
+    const int member = team * kMembers + rank, nActive = boards * kMembers; // (cleaning shares)
 
+    int* gaveUp = reinterpret_cast<int*>(smem + kFlagOff);
+    if (tid == 0) *gaveUp = 0;
     // the image's halo entries stay zero for the whole launch: staging rewrites interior entries only
     for (int i = lane; i < kImage / 16; i += 64) reinterpret_cast<u32x4*>(img)[i] = u32x4{0u, 0u, 0u, 0u};
 
@@ -125,23 +150,13 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         const int m = (h * FR + f) * 16 + li;
         abase[f] = ((m < 81 ? entryOf(m) : 11) - 11) * 16; // 11: every tap reads the zero entries
     }
-    // staging: item k of a lane = piece lane / 8 of row k*8 + lane % 8 of this wave's chunk.  Eight consecutive
-    // lanes write ONE piece of eight consecutive rows: consecutive entries of one plane, distinct banks (a lane per
-    // piece of one row would put the eight pieces of an entry, 256-byte-aligned planes apart, on the same banks)
-    // Only the board rows this member's fragments and their 3x3 neighbours touch are fetched: squares 0..57 for the
-    // first row half (fragments 0-2 = squares 0..47, + their neighbours below), 38..80 for the second (63 % of the board on
-    // average: a handed-off tile arrives at ~70 GB/s per CU, MI355X_MICROARCH.md handoff-payload)
-    const int stPiece = lane >> 3;
+    // staging.  Only the board rows this member's fragments and their 3x3 neighbours touch are fetched: squares 0..57
+    // for the first row half of a 32-member team (fragments 0-2 = squares 0..47, + their neighbours below), 38..80
+    // for the second
     // (rows of the member's fragments -1 / +1 board row: 16*first - 10 .. 16*last + 25, clipped to the board)
     const int rowLo = (h * FR) * 16 - 10 > 0 ? (h * FR) * 16 - 10 : 0;
     const int rowHi = (h * FR + FR) * 16 + 9 < 80 ? (h * FR + FR) * 16 + 9 : 80;
-    int srcRow[kItems], dstOff[kItems];
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const int row = k * 8 + (lane & 7);
-        srcRow[k] = (row >= rowLo && row <= rowHi) ? row : -1;
-        dstOff[k] = stPiece * kPlane + entryOf(row < 81 ? row : 0) * 16;
-    }
+    auto entry16 = [](int row) { return (34 + row + ((row * 57) >> 9)) * 16; }; // entryOf(row) * 16, row < 128
     // K parts: after its MFMAs a wave parks its three accumulator fragments in INTERIOR entries of its own image (the
     // halo entries must stay zero; the next layer's staging rewrites every interior entry it reads): 16-byte slot
     // f*64 + lane -> piece slot / (8 FR), square slot % (8 FR) -- squares inside the rows this member stages
@@ -154,6 +169,20 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
     // output: lane (li, g) of fragment f holds channels ch0 .. ch0+3 of row (h*3+f)*16 + li
     const int ch0 = (j >> 2) * 64 + g * 16 + (j & 3) * 4;
     const int outOff = (ch0 >> 5) * 128 + (ch0 & 31) * 2; // byte offset of the hi pair inside a row; lo at +64
+    // ... in the evaluator's kF16x3 layout (layer 0's input, the last layer's output).  The hand-off images are this
+    // kernel's own.  A lane's piece of an image row = its four channels' hi halves + lo halves, 16 bytes; a row =
+    // [chunk kc][member j & 3][g & 1]: the pieces of one 32-channel chunk (which come from members 4 (kc / 2) .. + 3,
+    // lane groups g = 2 (kc & 1), + 1) are 128 contiguous bytes for the wave that reads that chunk, and a producing
+    // wave's store touches 2 x 32 bytes per row -- 32 line segments, not the 128 scattered 8-byte pieces of the
+    // evaluator's layout (write-through: a store is paid per segment; profiles/r03/README.md).
+    const int imgOff = (2 * (j >> 2) + (g >> 1)) * 128 + (j & 3) * 32 + (g & 1) * 16;
+    // staging from an image: a lane takes BOTH pieces (members jq = 2 jp, 2 jp + 1; 32 bytes apart) of group gq of
+    // row 16 k + lane % 16: channels 16 gq + 8 jp .. + 7 of the chunk = LDS piece 2 gq + jp whole (hi; + 4 lo), one
+    // 16-byte LDS write each; 16 consecutive lanes write 16 consecutive rows of one piece: distinct banks.
+    const int stGq = (lane >> 4) & 1, stJp = lane >> 5;
+    const int imgSrc = (2 * stJp) * 32 + stGq * 16; // inside the wave's chunk of a row
+    const int imgDst = (2 * stGq + stJp) * kPlane;
+    constexpr int kImgItems = 6; // 96 rows >= 81
 
     auto loadWeights = [&](const TeamLayer& L, u32x4 (&w)[9][2]) {
         const int nkc = L.kdim / 32;
@@ -172,59 +201,80 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 #endif
     u32x4 w[9][2];
     loadWeights(layers[0], w);
-    bool alive = true;
     for (int l = 0; l < nLayers; ++l) {
         const TeamLayer L = layers[l];
         const int nkc = L.kdim / 32;
         const size_t inRow = (size_t)L.kdim * 4, outRow = (size_t)L.cout * 4;
-        // ---- wait for the team's previous layer (layer 0 reads what the launch before this one wrote)
-        // (the poller's first poll returns behind its own weight requests of a moment ago -- a wave's loads return in
-        // order -- but the team needs that long to gather anyway: holding the poller's weights back until its poll had
-        // matched cost 17-23 %, profiles/r03/g_team_trunk_ab.txt)
+        // layer l reads image (l - 1) % 4 of the set and writes image l % 4; the last layer writes the evaluator's
+        const unsigned char* xPtr = l == 0 ? L.x : ho.set + (size_t)((l - 1) & 3) * ho.imageStride;
+        unsigned char* yPtr = l + 1 == nLayers ? L.y : ho.set + (size_t)(l & 3) * ho.imageStride;
+        unsigned char* oldPtr = l >= 2 ? ho.set + (size_t)((l - 2) & 3) * ho.imageStride : nullptr; // this member's output of layer l - 2
+        const unsigned char* resPtr = L.res ? oldPtr : nullptr;
+        const bool fromImage = l > 0, toImage = l + 1 < nLayers;
         TEAM_STAMP(0)
-        if (l > 0) {
-            if (tid == kThreads - 64) {
-                const u64 target = base + (u64)l * kMembers;
-                int spins = 0;
-                while (loadAgent(ctr) < target) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 4095) == 0 &&
-                        (spins > (1 << 22) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
-                        __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // bounded: ~1 s
-                        alive = false;
-                        break;
-                    }
-                }
-            }
-            alive = __syncthreads_and(alive ? 1 : 0) != 0; // (also: the polling wave's answer reaches every wave)
-            if (!alive) return;
-        }
-        // ---- this wave's chunk of the board -> its LDS image (agent-scope loads: never the L1 of this CU)
-        TEAM_STAMP(1)
-        // (waves 0..2 also request their residual rows now: one round trip, hidden behind the tile and the MFMAs)
+        // (waves 0..FR-1 also request their residual rows now -- their own stores of two layers ago, long landed)
         const int mOut = (h * FR + (wave < FR ? wave : 0)) * 16 + li;
-        const size_t rowOff = ((size_t)team * 81 + (mOut < 81 ? mOut : 0)) * outRow + outOff;
-        u64 resHi = 0, resLo = 0;
+        const size_t rowBase = ((size_t)team * 81 + (mOut < 81 ? mOut : 0)) * outRow; // (images: 256 channels, the same row size)
+        const size_t rowOff = rowBase + outOff;
+        const int rowImg = (int)rowBase + imgOff;
+        const rsrc_t xBuf = bufferOf(xPtr), yBuf = bufferOf(yPtr), oldBuf = bufferOf(oldPtr ? oldPtr : yPtr);
+        u32x4 resV = u32x4{0u, 0u, 0u, 0u};
         f32x4 biasV = f32x4{0.f, 0.f, 0.f, 0.f};
         if (wave < FR) {
             biasV = *asGlobal<f32x4>(L.bias + ch0);
-            if (L.res && mOut < 81) {
-                resHi = loadAgent(L.res + rowOff);
-                resLo = loadAgent(L.res + rowOff + 64);
-            }
+            if (resPtr && mOut < 81) resV = loadAgent16(oldBuf, rowImg);
         }
+        TEAM_STAMP(1)
+        // ---- this wave's chunk of the board -> its LDS image; a piece is there when neither of its halves is the
+        // sentinel (layer 0 reads the planes of the launch before this one: there at the first request)
         if (wave < nkc) {
-            u32x4 st[kItems];
-            const unsigned char* xb = L.x + (size_t)team * 81 * inRow + (size_t)wave * 128 + (size_t)stPiece * 16;
+            // item k of a lane = two 16-byte pieces of row 16 k + lane % 16 that make LDS piece 2 gq + jp (hi) and
+            // its lo twin: from an image the two members' [hi4 | lo4] (32 bytes apart), from the evaluator's layout
+            // (layer 0) the hi piece and the lo piece themselves (64 bytes apart)
+            u32x4 st[2 * kImgItems];
+            const int xb = team * 81 * (int)inRow + wave * 128 + (fromImage ? imgSrc : (2 * stGq + stJp) * 16);
+            const int second = fromImage ? 32 : 64;
+            unsigned pend = 0;
 #pragma unroll
-            for (int k = 0; k < kItems; ++k) {
-                st[k] = u32x4{0u, 0u, 0u, 0u};
-                if (srcRow[k] >= 0) st[k] = loadAgent16(xb + (size_t)srcRow[k] * inRow);
+            for (int k = 0; k < kImgItems; ++k) {
+                const int row = k * 16 + li;
+                if (row >= rowLo && row <= rowHi) pend |= 1u << k;
             }
-            waitLoads();
+            int spins = 0;
+            for (;;) {
+                asm volatile("" ::: "memory"); // every round asks memory again
 #pragma unroll
-            for (int k = 0; k < kItems; ++k)
-                if (srcRow[k] >= 0) *reinterpret_cast<u32x4*>(img + dstOff[k]) = st[k];
+                for (int k = 0; k < kImgItems; ++k)
+                    if ((pend >> k) & 1u) {
+                        const int src = xb + (k * 16 + li) * (int)inRow;
+                        st[2 * k] = loadAgent16(xBuf, src);
+                        st[2 * k + 1] = loadAgent16(xBuf, src + second);
+                    }
+#pragma unroll
+                for (int k = 0; k < kImgItems; ++k) {
+                    if (!((pend >> k) & 1u)) continue;
+                    const u32x4 a = st[2 * k], b = st[2 * k + 1];
+                    // (no word of a stored piece is all ones: the largest of the eight tells)
+                    const unsigned top = umax3(umax3(a.x, a.y, a.z), umax3(a.w, b.x, b.y), b.z > b.w ? b.z : b.w);
+                    if (top != 0xffffffffu) {
+                        unsigned char* d = img + imgDst + entry16(k * 16 + li);
+                        *reinterpret_cast<u32x4*>(d) = fromImage ? u32x4{a.x, a.y, b.x, b.y} : a;
+                        *reinterpret_cast<u32x4*>(d + 4 * kPlane) = fromImage ? u32x4{a.z, a.w, b.z, b.w} : b;
+                        pend &= ~(1u << k);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(pend != 0) == 0) break;
+                if ((++spins & 255) == 0 &&
+                    (spins > (1 << 20) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                    __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // bounded: ~1 s
+                    *gaveUp = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+#ifdef TEAM_STAMPS
+            if (blockIdx.x == 0 && lane == 0 && l >= 2 && l < 34) atomicAdd(&gTeamStamps[(l - 2) * 8 + 7], (u64)spins + 1);
+#endif
         }
         TEAM_STAMP(2)
         // (a wave reads only its own image: its own LDS writes are ordered before its reads, no barrier)
@@ -261,10 +311,14 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
             }
         }
         TEAM_STAMP(3)
-        // ---- add the K parts (fixed order: deterministic), waves 0..2 finish one row fragment each
+        // ---- add the K parts (fixed order: deterministic), waves 0..FR-1 finish one row fragment each
 #pragma unroll
         for (int f = 0; f < FR; ++f) *reinterpret_cast<f32x4*>(img + redOff[f]) = acc[f];
+        // (the sentinel stores of the layer before have landed: the argument at the head of the file wants that
+        // before C(n, l); they were issued in front of this layer's tile requests, whose data the MFMAs above used)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (*gaveUp) return; // (a wave whose wait ran out reaches every wave of the member; the others see `status`)
         TEAM_STAMP(4)
         if (wave < FR) {
             const int ro = redOff[FR == 1 ? 0 : (wave < FR ? wave : 0)];
@@ -275,10 +329,10 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaf(sum[r], L.accScale, biasV[r]);
-                if (L.res) {
+                if (resPtr) {
                     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                    const f16x4 rh = __builtin_bit_cast(f16x4, resHi);
-                    const f16x4 rl = __builtin_bit_cast(f16x4, resLo);
+                    const f16x4 rh = __builtin_bit_cast(f16x4, (u64)resV.x | ((u64)resV.y << 32));
+                    const f16x4 rl = __builtin_bit_cast(f16x4, (u64)resV.z | ((u64)resV.w << 32));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += (float)rh[r] + (float)rl[r];
                 }
@@ -286,22 +340,34 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                 unsigned h01, l01, h23, l23;
                 splitPair(v[0], v[1], floorV, h01, l01);
                 splitPair(v[2], v[3], floorV, h23, l23);
-                storeAgent(L.y + rowOff, (u64)h01 | ((u64)h23 << 32));
-                storeAgent(L.y + rowOff + 64, (u64)l01 | ((u64)l23 << 32));
+                if (toImage) {
+                    storeAgent16(yBuf, rowImg, u32x4{h01, h23, l01, l23});
+                } else {
+                    storeAgent(yPtr + rowOff, (u64)h01 | ((u64)h23 << 32));
+                    storeAgent(yPtr + rowOff + 64, (u64)l01 | ((u64)l23 << 32));
+                }
+                // behind the barrier above = C(n, l), every wave of the member has its input: the sentinel goes
+                // back over this member's output of layer l - 2 (see the head of the file)
+                if (oldPtr) storeAgent16(oldBuf, rowImg, u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have left before the barrier below
         }
         TEAM_STAMP(5)
-        __syncthreads(); // every storing wave has drained, every parked accumulator has been read
+#ifndef TEAM_EXP_NO_B2
+        __syncthreads(); // every parked accumulator has been read: the next layer's staging may overwrite them
+#endif
         TEAM_STAMP(6)
-        if (l + 1 < nLayers) {
-            if (tid == 0) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // the next layer's weights go out now (read-only: plain loads) and are in flight while the team gathers;
-            // issued BEHIND this wave's output stores and their drain, which would otherwise wait for them too.
-            // (Two register sets, the next layer's records requested behind this layer's tile requests instead:
-            // no faster -- a layer's 147 KB of records + 51 KB of tile are 3.1k cycles of this CU's L1 wherever
-            // they are placed -- and the counted wait it needs is fragile.)
-            loadWeights(layers[l + 1], w);
+        // ---- the next layer's records go out BEHIND the member's output stores (requested in front of them -- by
+        // any wave of the member: a workgroup has one address path -- they held the stores, and with them the team,
+        // back by the time 147 KB of records take to arrive: profiles/r03/README.md).
+        if (l + 1 < nLayers) loadWeights(layers[l + 1], w);
+        // the image the launch before this one left behind in the other set gets its sentinel back
+        if (l == 0) {
+            const size_t nPieces = (size_t)ho.cleanBoards * (81 * 1024 / 16);
+            // (agent-scope stores like every other access to an image: plain stores here were not seen by the
+            // agent-scope loads of the launch after the next on another XCD -- stale pieces, taken for new ones)
+            const rsrc_t other = bufferOf(ho.other + (size_t)((nLayers - 2) & 3) * ho.imageStride);
+            for (size_t i = (size_t)member * kThreads + tid; i < nPieces; i += (size_t)nActive * kThreads)
+                storeAgent16(other, (int)(i * 16), u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
         }
     }
 }
@@ -316,8 +382,9 @@ int teamMembers(int boards) {
     static const int force = [] { const char* e = getenv("NSG_TEAM_MEMBERS"); return e ? atoi(e) : 0; }();
     if (boards > 8) return 16;
     if (force == 16) return 16;
+    if (force == 48) return boards <= 5 ? 48 : 32;
     if (force == 32 || force == 96) return (force == 96 && boards > 2) ? 32 : force;
-    return boards == 1 ? 96 : 32;
+    return boards <= 2 ? 96 : 32;
 }
 
 bool teamTrunkSupports(int channels, int stemKdim, int boards) {
@@ -328,36 +395,46 @@ bool teamTrunkSupports(int channels, int stemKdim, int boards) {
 void teamTrunkDumpStamps() {
     u64 h[32 * 8];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gTeamStamps), sizeof(h)) != hipSuccess) return;
-    double d[7] = {0};
+    double d[7] = {0}, tries = 0;
+    for (int l = 0; l < 31; ++l) tries += (double)h[l * 8 + 7];
+    fprintf(stderr, "team stamps: %.2f tile request rounds per layer, the member's eight waves together\n", tries / 31);
+    u64 zero[32 * 8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(gTeamStamps), zero, sizeof(zero));
     for (int l = 0; l < 31; ++l) {
         for (int i = 0; i < 6; ++i) d[i] += (double)(h[l * 8 + i + 1] - h[l * 8 + i]);
         d[6] += (double)(h[(l + 1) * 8] - h[l * 8 + 6]);
     }
-    fprintf(stderr, "team stamps (cycles/layer, member 0 lane 0): wait %.0f  issue-tile %.0f  mfma %.0f  red-write %.0f  reduce+epilogue %.0f  barrier %.0f  arrive+weights %.0f\n",
+    fprintf(stderr, "team stamps (cycles/layer, member 0 lane 0): residual request %.0f  tile (wait + stage) %.0f  mfma %.0f  next weights + clean + park + barrier %.0f  reduce + epilogue %.0f  barrier %.0f  loop %.0f\n",
             d[0] / 31, d[1] / 31, d[2] / 31, d[3] / 31, d[4] / 31, d[5] / 31, d[6] / 31);
 }
 #endif
 
-hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, unsigned long long* counters,
-                           const TeamBases& bases, int* status, hipStream_t stream) {
-    if (nLayers < 1 || boards < 1 || boards > kTeamMaxBoards) return hipErrorInvalidValue;
+hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, const TeamHandoff& handoff, int* status,
+                           hipStream_t stream) {
+    if (nLayers < 3 || boards < 1 || boards > kTeamMaxBoards || !handoff.set || !handoff.other ||
+        handoff.imageStride < (size_t)boards * 81 * 1024 || handoff.imageStride < (size_t)handoff.cleanBoards * 81 * 1024)
+        return hipErrorInvalidValue;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)teamTrunkKernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)teamTrunkKernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)teamTrunkKernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)teamTrunkKernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return e;
         attr = true;
     }
     if (teamMembers(boards) == 96)
         hipLaunchKernelGGL(teamTrunkKernel<1>, dim3(boards * 96), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
-                           counters, bases, status);
+                           handoff, status);
+    else if (teamMembers(boards) == 48)
+        hipLaunchKernelGGL(teamTrunkKernel<2>, dim3(boards * 48), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
+                           handoff, status);
     else if (teamMembers(boards) == 16)
         hipLaunchKernelGGL(teamTrunkKernel<6>, dim3(boards * 16), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
-                           counters, bases, status);
+                           handoff, status);
     else
         hipLaunchKernelGGL(teamTrunkKernel<3>, dim3(8 * 32), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
-                           counters, bases, status);
+                           handoff, status);
     return hipGetLastError();
 }
 

@@ -315,10 +315,12 @@ struct nsg_evaluator {
     // Team trunk (kernels/team_trunk.hip): up to eight boards, every 3x3 layer in one persistent launch, kF16x3
     // arithmetic.  NSG_TEAM_TRUNK=0 switches it off.  One team launch per DEVICE at a time (teamToken below).
     DevBuf teamLayers;       // nsg::TeamLayer list (stem + 2 per block) on the kF16x3 copy of the trunk
-    DevBuf teamCounters;     // 8 x 64 B: one monotonic 64-bit counter per team
+    DevBuf teamSets;         // 2 hand-off sets x 4 images x teamBoards boards (nsg::TeamHandoff)
+    int teamBoards = 0;      // boards an image holds: min(batchMax, kTeamMaxBoards)
+    int teamSet = 0;         // the set the next launch writes
+    int teamDirty[2] = {0, 0}; // boards of each set that do not hold the sentinel
     int teamLayerCount = 0;
     int teamEnabled = 1;
-    nsg::TeamBases teamBases{};
     int* teamStatusHost = nullptr; // host-mapped: raised by the kernel when a bounded spin runs out
     int* teamStatusDev = nullptr;
     bool teamLast = false;   // the most recent forward ran the team trunk
@@ -465,10 +467,17 @@ int enqueueTeam(nsg_evaluator* ev, int B, hipStream_t s, hipEvent_t trunkBegin, 
     {
         Range r("nsg.trunk");
         if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
-        NSG_HIP(nsg::launchTeamTrunk((const nsg::TeamLayer*)ev->teamLayers.p, ev->teamLayerCount, B,
-                                     (unsigned long long*)ev->teamCounters.p, ev->teamBases, ev->teamStatusDev, s));
-        for (int t = 0; t < B; ++t)
-            ev->teamBases.v[t] += (unsigned long long)(ev->teamLayerCount - 1) * (unsigned long long)nsg::teamMembers(B);
+        nsg::TeamHandoff ho;
+        ho.imageStride = (size_t)ev->teamBoards * 81 * 1024;
+        const size_t setBytes = 4 * ho.imageStride;
+        ho.set = (unsigned char*)ev->teamSets.p + (size_t)ev->teamSet * setBytes;
+        ho.other = (unsigned char*)ev->teamSets.p + (size_t)(1 - ev->teamSet) * setBytes;
+        ho.cleanBoards = ev->teamDirty[1 - ev->teamSet];
+        NSG_HIP(nsg::launchTeamTrunk((const nsg::TeamLayer*)ev->teamLayers.p, ev->teamLayerCount, B, ho,
+                                     ev->teamStatusDev, s));
+        ev->teamDirty[1 - ev->teamSet] = 0;
+        ev->teamDirty[ev->teamSet] = B;
+        ev->teamSet = 1 - ev->teamSet;
         if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
     }
     void* x = (ev->blocks % 2 == 1) ? ev->act[2].p : ev->act[0].p; // the buffer rotation of the layer list
@@ -870,10 +879,12 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
         }
         if ((rc = ev->teamLayers.alloc(host.size() * sizeof(nsg::TeamLayer), false))) return rc;
         NSG_HIP(hipMemcpy(ev->teamLayers.p, host.data(), host.size() * sizeof(nsg::TeamLayer), hipMemcpyHostToDevice));
-        if (!ev->teamCounters.p) {
-            if ((rc = ev->teamCounters.alloc(nsg::kTeamMaxBoards * 64, true))) return rc;
-            ev->teamBases = nsg::TeamBases{};
-        }
+        ev->teamBoards = ev->batchMax < nsg::kTeamMaxBoards ? ev->batchMax : nsg::kTeamMaxBoards;
+        const size_t setsBytes = 2 * 4 * (size_t)ev->teamBoards * 81 * 1024;
+        if ((rc = ev->teamSets.alloc(setsBytes, false))) return rc;
+        NSG_HIP(hipMemset(ev->teamSets.p, 0xff, setsBytes));
+        ev->teamSet = 0;
+        ev->teamDirty[0] = ev->teamDirty[1] = 0;
         if (!ev->teamStatusHost) {
             NSG_HIP(hipHostMalloc((void**)&ev->teamStatusHost, 64, hipHostMallocMapped));
             *ev->teamStatusHost = 0;
