@@ -1,46 +1,53 @@
-// team_trunk.hip -- the whole 3x3 trunk of up to eight boards in ONE persistent launch, for the smallest
+// team_trunk.hip -- the whole 3x3 trunk of up to sixteen boards in ONE persistent launch, for the smallest
 // batches (the engine's leaf batches at the start of a search, batch-1 analysis).
 //
 // Why: at one board a 3x3 layer is 2.36 MB of weights against 15 MFLOP -- a weight-bandwidth problem.  The
 // per-layer tile kernels give a board to 24 workgroups that each stream 622 KB of records through ONE L1 for 108
 // MFMAs per wave, behind a launch boundary, a kernel-start latency and a tile round trip per layer: 14.5 us per
-// layer.  Here a board belongs to a TEAM of 32 workgroups (one per CU; blocks b and b + 8 share an XCD under the
-// observed round-robin placement, so a team is the blocks of one residue mod 8 -- speed only, nothing depends on
-// it).  Member (j, h) computes 16 output channels (weight fragment j) of one half of the board's rows: its
-// eight waves split K by 32-channel chunk, so a wave's share of a layer's weights is 18 records = 18 KiB = 72
-// registers -- small enough to be requested one LAYER ahead, while the team waits for the layer before.  Per
-// layer a member then loads its input (each wave its own chunk of the whole board, into a wave-private LDS
-// image: no workgroup barrier), runs 81 MFMAs per wave, adds the eight K parts through LDS, finishes three row
-// fragments (bias, residual, ReLU, f16 hi/lo split) and hands its 3 KB of output to the team.
+// layer.  Here a board belongs to a TEAM of 96 / 48 / 32 / 16 workgroups (teamMembers() below; one per CU).  Member
+// (j, h) computes 16 output channels (weight fragment j) of row group h -- 1, 2, 3 or all 6 of the board's 16-row
+// fragments: its eight waves split K by 32-channel chunk, so a wave's share of a layer's weights is 18 records =
+// 18 KiB = 72 registers, requested as soon as the layer before has stored its output.  Per layer a member loads
+// its input (each wave its own chunk of the rows it needs, into a wave-private LDS image: no workgroup barrier),
+// runs 27 MFMAs per wave and row fragment, adds the eight K parts through LDS, finishes its row fragments (bias,
+// residual, ReLU, f16 hi/lo split) and hands its output to the team.  (A 32-member team is the blocks of one
+// residue mod 8: they share an XCD, and its L2 the weights, under the observed round-robin placement -- speed only.)
 //
-// Hand-off: the payload is its own flag.  The layers but the last write into four rotating buffers (`TeamHandoff::
-// set`, [boards][81][256] kF16x3 images; layer l writes image l % 4) that hold the SENTINEL -- all bits set -- where
-// nothing has been handed over yet.  A producer stores its output with 8-byte agent-scope relaxed atomic stores
-// (sc1, write-through; four channels' hi halves or lo halves each: single-copy atomic) and does not wait for them.
-// A consumer requests its input tile with 16-byte agent-scope loads (sc1, never this CU's L1), checks one word of
-// each 8-byte half against the sentinel and requests the pieces that were not there yet again, until all are.  No
-// value a layer stores contains the sentinel: a stored half is an f16 of a number clamped to +-65000, or of the
-// difference between such a number and its f16 rounding; 0xffff is a NaN.  A layer therefore costs ONE one-way trip of
-// its payload on the critical path (the counter protocol this replaces paid for a store drain, an atomic add, a
-// poll and then the tile's round trip: profiles/r03/README.md).
+// Hand-off: the payload is its own flag.  The layers but the last write into four rotating images (`TeamHandoff::
+// set`, [boards][81 rows][1024 B]; layer l writes image l % 4) that hold the SENTINEL -- all bits set -- where
+// nothing has been handed over yet.  A producing lane stores its piece -- four channels' f16 hi halves and lo halves,
+// 16 bytes -- with one agent-scope store (sc1, write-through) and does not wait for it.  A consumer requests its
+// input tile with 16-byte agent-scope loads (sc1, never this CU's L1), compares every word of a piece with the
+// sentinel and requests the pieces that were not there yet again, until all are.  No word a layer stores is the
+// sentinel: a stored half is an f16 of a number clamped to +-65000, or of the difference between such a number and
+// its f16 rounding; 0xffff is a NaN.  (So a piece need not even arrive in one piece.)  A layer therefore costs ONE
+// one-way trip of its payload on the critical path; the counter protocol this replaced paid for a store drain, an
+// atomic add, a poll and then the tile's round trip (profiles/r03/README.md).
+//   The images are this kernel's own (layer 0 reads, the last layer writes the evaluator's kF16x3 layout): a row is
+// [chunk][member % 4][lane group % 2] pieces, so that a wave's chunk of a row is 128 contiguous bytes and a producing
+// wave's store touches 2 x 32 bytes of a row.  In the evaluator's layout the same store is 128 scattered 8-byte
+// pieces per wave, and a write-through store is paid per segment it touches: +12 % at 3-16 boards.
 //   Reuse of an image.  Write C(n, l) for the moment ALL EIGHT waves of member n have their input of layer l (the
-// workgroup barrier behind the MFMAs; the input includes every neighbour's -- every member's whose rows n reads,
-// which are the members that read n's -- output of layer l - 1) and F(n, l) > C(n, l) for its output stores of layer l.  At C(n, l) member n puts the sentinel back over its own output of layer l - 2 (the residual
-// of layer l, requested before the tile, has arrived by then): every neighbour m has stored layer l - 1, so has read
-// layer l - 2.  The waves that store the sentinel wait for all their memory operations (vmcnt(0)) at C(n, l + 1),
-// before F(n, l + 1).  A member m that looks at that place again -- for layer l + 2's output, after F(m, l + 2) >
-// C(m, l + 2) > F(n, l + 1) -- finds the sentinel or the new value, never the old one; and n overwrites layer l - 2's
-// image with layer l + 2's after C(n, l + 2) > F(m, l + 1) > C(m, l + 1): after every neighbour has read layer l.
-//   Across launches.  The last layer but one's image (nLayers - 2) is still being read when the launch ends: it is
-// left as it is.  Two sets alternate between launches and a launch restores the sentinel in that one image of the
-// OTHER set (`cleanBoards` boards of it; the kernel boundary orders that against the set's next use).
+// workgroup barrier behind the MFMAs; the input includes the output of layer l - 1 of every neighbour -- every member
+// whose rows n reads, which are the members that read n's) and F(n, l) > C(n, l) for n's output stores of layer l.
+// Behind C(n, l) member n puts the sentinel back over its own output of layer l - 2 (the residual of layer l,
+// requested before the tile, has arrived by then): every neighbour m has stored layer l - 1, so has read layer
+// l - 2.  The storing waves wait for all their memory operations (vmcnt(0)) before C(n, l + 1) < F(n, l + 1).  A member
+// m that looks at that place again -- for layer l + 2's output, after F(m, l + 2) > C(m, l + 2) > F(n, l + 1) -- finds
+// the sentinel or the new value, never the old one; and n overwrites layer l - 2's image with layer l + 2's after
+// C(n, l + 2) > F(m, l + 1) > C(m, l + 1): after every neighbour has read layer l.
+//   Across launches.  The last layer but one's image is still being read when the launch ends: it is left as it is.
+// Two sets alternate between launches and a launch restores the sentinel in that one image of the OTHER set
+// (`cleanBoards` boards of it; the kernel boundary orders that against the set's next use).
+//   Every access to an image is agent-scope (sc1), the sentinel stores too: a plain store's line can sit in one
+// XCD's L2 while another XCD's sc1 load reads the stale piece behind it from memory -- and takes it for a new one.
 //   Every spin is bounded: a member that waits longer than ~1 s raises `status` (host-mapped) and the launch unwinds;
 // the host turns that into an error at await.  Two team launches must not share a device at the same time (each
 // would hold CUs the other's unscheduled members need): nsg_capi.hip keeps one token per device.
 //
-// Arithmetic: kF16x3 (split f16 hi/lo, three f16 MFMAs per MAC, f32 accumulate) on the kF16x3 records and
-// activation layout the evaluator keeps for batches without an MX plan -- a channel subset can be written
-// without its neighbours (the MX formats share one exponent per 32 channels across FOUR members' outputs).
+// Arithmetic: kF16x3 (split f16 hi/lo, three f16 MFMAs per MAC, f32 accumulate) on the kF16x3 records the evaluator
+// keeps for batches without an MX plan -- a channel subset can be written without its neighbours (the MX formats
+// share one exponent per 32 channels across FOUR members' outputs).
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -374,17 +381,16 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 
 } // namespace
 
-// Members per board: 96 (one row fragment each) for a single board, 32 (three each) for two to eight (measured,
-// profiles/r03/g_team_trunk_members.txt: one board 4.76k against 3.34k evals/s, two boards 6.31k against 6.71k).
-// NSG_TEAM_MEMBERS = 32 | 96 overrides (96: one or two boards only).
-// Nine to sixteen boards: 16 members per board, one weight fragment x the whole board each.
+// Members per board = 16 weight fragments x row groups, as many as fit the chip's 256 CUs (a member owns a CU: 147 KB
+// of LDS): 96 (one row fragment each) for one or two boards, 48 (two) for three to five, 32 (three) for six to eight,
+// 16 (the whole board) for nine to sixteen.  Measured, evals/s at 2 / 3 / 4 / 5 boards: 96 members 11.2k / - / - / -,
+// 48 members 9.2k / 13.5k / 17.7k / 21.6k, 32 members 7.8k / 11.5k / 15.4k / 18.8k; 6 / 8 boards: 32 members
+// 22.5k / 29.3k, 16 members 16.2k / 21.3k (profiles/r03/g_team_trunk_members.txt).
+// NSG_TEAM_MEMBERS = 16 | 32 | 48 | 96 asks for fewer members than that (or the same).
 int teamMembers(int boards) {
     static const int force = [] { const char* e = getenv("NSG_TEAM_MEMBERS"); return e ? atoi(e) : 0; }();
-    if (boards > 8) return 16;
-    if (force == 16) return 16;
-    if (force == 48) return boards <= 5 ? 48 : 32;
-    if (force == 32 || force == 96) return (force == 96 && boards > 2) ? 32 : force;
-    return boards <= 2 ? 96 : 32;
+    const int most = boards <= 2 ? 96 : boards <= 5 ? 48 : boards <= 8 ? 32 : 16;
+    return (force == 16 || force == 32 || force == 48 || force == 96) && force < most ? force : most;
 }
 
 bool teamTrunkSupports(int channels, int stemKdim, int boards) {

@@ -312,7 +312,7 @@ struct nsg_evaluator {
 
     void* trunkOut = nullptr; // which act[] holds the trunk output of the last forward
 
-    // Team trunk (kernels/team_trunk.hip): up to eight boards, every 3x3 layer in one persistent launch, kF16x3
+    // Team trunk (kernels/team_trunk.hip): up to sixteen boards, every 3x3 layer in one persistent launch, kF16x3
     // arithmetic.  NSG_TEAM_TRUNK=0 switches it off.  One team launch per DEVICE at a time (teamToken below).
     DevBuf teamLayers;       // nsg::TeamLayer list (stem + 2 per block) on the kF16x3 copy of the trunk
     DevBuf teamSets;         // 2 hand-off sets x 4 images x teamBoards boards (nsg::TeamHandoff)
@@ -456,7 +456,7 @@ void releaseTeamToken(nsg_evaluator* ev) {
     if (gTeamOwner[ev->gpu & 63] == ev) gTeamOwner[ev->gpu & 63] = nullptr;
 }
 
-// The whole forward of a batch of at most eight boards with the team trunk.
+// The whole forward of a batch of at most kTeamMaxBoards boards with the team trunk.
 int enqueueTeam(nsg_evaluator* ev, int B, hipStream_t s, hipEvent_t trunkBegin, hipEvent_t trunkEnd) {
     const int prec = nsg::kF16x3;
     ev->lastTrunkPrec = prec;
@@ -647,7 +647,7 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     hipEvent_t* e = prof ? &ev->ev[ev->evUsed] : nullptr;
     if (prof) NSG_HIP(hipEventRecord(e[0], s));
 
-    // The smallest batches: every 3x3 layer in one persistent launch, a board per team of 32 workgroups
+    // The smallest batches: every 3x3 layer in one persistent launch, a board per team of 16-96 workgroups
     // (kernels/team_trunk.hip), when no tuning override asks for a particular per-layer plan and no other evaluator
     // has a team launch in flight on this device.
     ev->teamLast = false;

@@ -845,12 +845,12 @@ def test_slab_split_tiles(nsg, oracle, monkeypatch, channels, batch, ss, mx):
 @pytest.mark.parametrize("precision", ["f16m6", "f16x3"])
 @pytest.mark.parametrize("blocks", [2, 5])
 def test_team_trunk_small_batches(nsg, oracle, monkeypatch, precision, blocks):
-    """Batches of up to eight boards: every 3x3 layer in ONE persistent launch, a board per team of 32 workgroups
-    that hand their 16-channel output slices to each other through agent-scope stores / loads and one counter per
-    team (kernels/team_trunk.hip), in the kF16x3 arithmetic.  Against the oracle, against the per-layer kernels of
-    the same arithmetic (NSG_TEAM_TRUNK=0: only the f32 summation order differs), bit-identical whatever else is in
-    the batch and from launch to launch (the team counters are never reset), for batch sizes 1..8 (96 or 32
-    workgroups per board) and 9..16 (16 per board)."""
+    """Batches of up to sixteen boards: every 3x3 layer in ONE persistent launch, a board per team of 96 / 48 / 32 / 16
+    workgroups that hand their 16-channel output slices to each other through agent-scope stores / loads, the payload
+    being its own flag (kernels/team_trunk.hip), in the kF16x3 arithmetic.  Against the oracle, against the per-layer
+    kernels of the same arithmetic (NSG_TEAM_TRUNK=0: only the f32 summation order differs), bit-identical whatever
+    else is in the batch and from launch to launch (the hand-off images alternate and are restored between launches
+    of different sizes), for batch sizes 1..8 and 9..16."""
     ev, blob = make(nsg, blocks, 256, 8, precision=precision, seed=300 + blocks)
     net = oracle.net(blob)
     bb = nsg.synth.random_batch(8, 86, seed=301, garbage=True)
@@ -893,10 +893,36 @@ def test_team_trunk_small_batches(nsg, oracle, monkeypatch, precision, blocks):
     check((p16, v16, d16), tuple(r[:16] for r in ref17), 2e-4)
     p9, v9, d9 = big.compute_blocking(bb17[:9])
     np.testing.assert_array_equal(p9, p16[:9])
-    p8, _, _ = big.compute_blocking(bb17[:8])  # 32 workgroups per board: another summation order of the K parts? no: the same
+    p8, _, _ = big.compute_blocking(bb17[:8])  # 32 workgroups per board
     assert float(np.abs(p8 - p16[:8]).max()) < 1e-4
     big.compute_blocking(bb17)
     assert big.last_plan()["waves_per_group"] != 8
+
+
+def test_team_trunk_handoff_images_across_launches(nsg):
+    """The team trunk's hand-off images are reused within a launch (four rotate) and across launches (two sets
+    alternate, a launch restores what the one before left behind): a stale piece taken for a new one, or a piece
+    missed, shows as a wrong board.  Sixty launches of changing size over changing selections of sixteen boards, some
+    back to back without a host wait: every board's outputs are the bits of its first evaluation, whatever ran before,
+    whichever slot it sits in and however many workgroups share its board (96 / 48 / 32 / 16)."""
+    ev, _ = make(nsg, 3, 256, 16, precision="f16m6", seed=910)
+    bb = nsg.synth.random_batch(16, 86, seed=911, garbage=True)
+    p0, v0, d0 = ev.compute_blocking(bb)
+    assert ev.last_plan()["waves_per_group"] == 8 and ev.last_plan()["k_split"] == 8  # the team trunk
+    rng = np.random.default_rng(912)
+    for step in range(60):
+        n = int(rng.integers(1, 17))
+        pick = rng.permutation(16)[:n]
+        if step % 4 == 3:  # device-resident, three forwards queued behind each other
+            ev.upload_features(bb[pick])
+            for _ in range(3):
+                ev.forward_resident(n)
+            p, v, d = ev.download_outputs(n)
+        else:
+            p, v, d = ev.compute_blocking(bb[pick])
+        np.testing.assert_array_equal(p, p0[pick], err_msg=f"step {step}: {n} boards {pick.tolist()}")
+        np.testing.assert_allclose(v, v0[pick], rtol=0, atol=1e-6)  # (the value MLP's plan follows the batch size)
+        np.testing.assert_allclose(d, d0[pick], rtol=0, atol=1e-6)
 
 
 def test_team_trunk_two_evaluators_share_a_device(nsg, oracle):
