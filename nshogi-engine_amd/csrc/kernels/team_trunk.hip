@@ -127,10 +127,7 @@ __device__ __forceinline__ void splitPair(float a, float b, float floorV, unsign
 __device__ u64 gTeamStamps[32 * 8];
 #endif
 
-// FR = row fragments per member: 3 (a board = 16 weight fragments x 2 row halves = 32 members, up to eight boards) or
-// 1 (16 x 6 = 96 members per board, a single board -- the launch allows two --: a third of the MFMAs, fragment reads and tile rows per member,
-// and the epilogue of one fragment; the members of a board then sit on every XCD, which costs a hand-off nothing
-// measurable once the payload is stored sc1 -- it leaves the producer's L2 either way).
+// FR = row fragments per member (1, 2, 3 or all 6: 96, 48, 32 or 16 members per board).
 template <int FR>
 __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* __restrict__ layers, int nLayers,
                                                                int boards, TeamHandoff ho, int* status) {
@@ -359,9 +356,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
             }
         }
         TEAM_STAMP(5)
-#ifndef TEAM_EXP_NO_B2
         __syncthreads(); // every parked accumulator has been read: the next layer's staging may overwrite them
-#endif
         TEAM_STAMP(6)
         // ---- the next layer's records go out BEHIND the member's output stores (requested in front of them -- by
         // any wave of the member: a workgroup has one address path -- they held the stores, and with them the team,

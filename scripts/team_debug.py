@@ -7,7 +7,7 @@ nsg = importlib.import_module("nshogi-engine_amd")
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 blob = nsg.weights.to_blob(nsg.weights.make_random(blocks, 256, seed=300 + blocks, bn="random"))
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
-maxb = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+maxb = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 bb = nsg.synth.random_batch(maxb, 86, seed=301, garbage=True)
 ev = nsg.Evaluator(0, maxb, 86, precision=prec); ev.load_memory(blob)
 first = {n: ev.compute_blocking(bb[:n])[0] for n in (maxb, 1)}  # the team trunk is the first thing this process runs
@@ -20,7 +20,7 @@ for n, p in first.items():
     if err.max() > 1e-3:
         b = int(err.max(axis=1).argmax()); e = err[b].reshape(-1, 81)
         print("   board", b, "bad squares", np.nonzero(e.max(axis=0) > 1e-3)[0].tolist()[:81], "bad policy planes", np.nonzero(e.max(axis=1) > 1e-3)[0].tolist())
-for n in [x for x in (8, 1, 2, 3, 12, 16, 1, 8) if x <= maxb]:
+for n in [x for x in (8, 1, 2, 3, 12, 16, 17, 32, 25, 1, 8) if x <= maxb]:
     p, v, d = ev.compute_blocking(bb[:n])
     err = np.abs(p - po[:n]).reshape(n, -1)
     print(n, ev.last_plan()["row_split"], "max err per board", np.round(err.max(axis=1), 4).tolist())
