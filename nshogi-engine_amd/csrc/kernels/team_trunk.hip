@@ -186,16 +186,20 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
     const int stGq = (lane >> 4) & 1, stJp = lane >> 5;
     const int imgSrc = (2 * stJp) * 32 + stGq * 16; // inside the wave's chunk of a row
     const int imgDst = (2 * stGq + stJp) * kPlane;
-    constexpr int kImgItems = 6; // 96 rows >= 81
+    // items (16 rows each) a member stages: the rows of its fragments and one board row either side = at most FR + 2
+    // consecutive items from item h * FR - 1 on
+    constexpr int kImgItems = FR + 2 < 6 ? FR + 2 : 6;
+    const int item0 = h * FR - 1 > 0 ? (h * FR - 1 < 6 - kImgItems ? h * FR - 1 : 6 - kImgItems) : 0;
 
     auto loadWeights = [&](const TeamLayer& L, u32x4 (&w)[9][2]) {
         const int nkc = L.kdim / 32;
         const NSG_GLOBAL u32x4* wp = asGlobal<u32x4>(L.w) + ((size_t)wave * 18 * 16 + j) * 64 + lane; // record q = (chunk*9 + tap)*2 + s, 16 fragments
+        if (wave < nkc) { // (uniform: a branch, not a select that would need the loaded value at once)
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                w[t][s] = wave < nkc ? wp[(size_t)(t * 2 + s) * 16 * 64] : u32x4{0u, 0u, 0u, 0u};
+                for (int s = 0; s < 2; ++s) w[t][s] = wp[(size_t)(t * 2 + s) * 16 * 64];
+        }
     };
 
 #ifdef TEAM_STAMPS
@@ -203,6 +207,9 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 #else
 #define TEAM_STAMP(I)
 #endif
+    // (A second record set for the 96-member teams, filled behind a layer's first round of tile requests so that the
+    // next layer's tile does not wait behind its 147 KB of records: measured 15 % slower, one board 4.87k against 5.70k
+    // evals/s -- the records then sit in front of the layer's output stores.  profiles/r03/README.md)
     u32x4 w[9][2];
     loadWeights(layers[0], w);
     for (int l = 0; l < nLayers; ++l) {
@@ -218,9 +225,8 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         TEAM_STAMP(0)
         // (waves 0..FR-1 also request their residual rows now -- their own stores of two layers ago, long landed)
         const int mOut = (h * FR + (wave < FR ? wave : 0)) * 16 + li;
-        const size_t rowBase = ((size_t)team * 81 + (mOut < 81 ? mOut : 0)) * outRow; // (images: 256 channels, the same row size)
-        const size_t rowOff = rowBase + outOff;
-        const int rowImg = (int)rowBase + imgOff;
+        const int rowBase = (team * 81 + (mOut < 81 ? mOut : 0)) * (int)outRow; // (images: 256 channels, the same row size)
+        const int rowImg = rowBase + imgOff;
         const rsrc_t xBuf = bufferOf(xPtr), yBuf = bufferOf(yPtr), oldBuf = bufferOf(oldPtr ? oldPtr : yPtr);
         u32x4 resV = u32x4{0u, 0u, 0u, 0u};
         f32x4 biasV = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -241,19 +247,20 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
             unsigned pend = 0;
 #pragma unroll
             for (int k = 0; k < kImgItems; ++k) {
-                const int row = k * 16 + li;
+                const int row = (item0 + k) * 16 + li;
                 if (row >= rowLo && row <= rowHi) pend |= 1u << k;
             }
-            int spins = 0;
-            for (;;) {
+            auto request = [&] {
                 asm volatile("" ::: "memory"); // every round asks memory again
 #pragma unroll
                 for (int k = 0; k < kImgItems; ++k)
                     if ((pend >> k) & 1u) {
-                        const int src = xb + (k * 16 + li) * (int)inRow;
+                        const int src = xb + ((item0 + k) * 16 + li) * (int)inRow;
                         st[2 * k] = loadAgent16(xBuf, src);
                         st[2 * k + 1] = loadAgent16(xBuf, src + second);
                     }
+            };
+            auto take = [&] {
 #pragma unroll
                 for (int k = 0; k < kImgItems; ++k) {
                     if (!((pend >> k) & 1u)) continue;
@@ -261,13 +268,17 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                     // (no word of a stored piece is all ones: the largest of the eight tells)
                     const unsigned top = umax3(umax3(a.x, a.y, a.z), umax3(a.w, b.x, b.y), b.z > b.w ? b.z : b.w);
                     if (top != 0xffffffffu) {
-                        unsigned char* d = img + imgDst + entry16(k * 16 + li);
+                        unsigned char* d = img + imgDst + entry16((item0 + k) * 16 + li);
                         *reinterpret_cast<u32x4*>(d) = fromImage ? u32x4{a.x, a.y, b.x, b.y} : a;
                         *reinterpret_cast<u32x4*>(d + 4 * kPlane) = fromImage ? u32x4{a.z, a.w, b.z, b.w} : b;
                         pend &= ~(1u << k);
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(pend != 0) == 0) break;
+            };
+            int spins = 0;
+            request();
+            take();
+            while (__builtin_amdgcn_ballot_w64(pend != 0) != 0) {
                 if ((++spins & 255) == 0 &&
                     (spins > (1 << 20) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
                     __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // bounded: ~1 s
@@ -275,6 +286,8 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                     break;
                 }
                 __builtin_amdgcn_s_sleep(8);
+                request();
+                take();
             }
 #ifdef TEAM_STAMPS
             if (blockIdx.x == 0 && lane == 0 && l >= 2 && l < 34) atomicAdd(&gTeamStamps[(l - 2) * 8 + 7], (u64)spins + 1);
@@ -347,8 +360,8 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                 if (toImage) {
                     storeAgent16(yBuf, rowImg, u32x4{h01, h23, l01, l23});
                 } else {
-                    storeAgent(yPtr + rowOff, (u64)h01 | ((u64)h23 << 32));
-                    storeAgent(yPtr + rowOff + 64, (u64)l01 | ((u64)l23 << 32));
+                    storeAgent(yPtr + (size_t)(rowBase + outOff), (u64)h01 | ((u64)h23 << 32));
+                    storeAgent(yPtr + (size_t)(rowBase + outOff) + 64, (u64)l01 | ((u64)l23 << 32));
                 }
                 // behind the barrier above = C(n, l), every wave of the member has its input: the sentinel goes
                 // back over this member's output of layer l - 2 (see the head of the file)
