@@ -440,17 +440,22 @@ __global__ void delayKernel(unsigned long long ticks) {
 // stream); otherwise it first waits, on the host, until the holder's stream has drained (at most one small-batch
 // forward) and takes the token.  Waiting -- not falling back to the per-layer kernels -- keeps the arithmetic of a
 // batch independent of timing: a self-play engine's two executors then produce the same bits in every run.
-// (The mutex is held across the wait: the holder cannot be destroyed under it, nsg_destroy releases the token first.)
+// The mutex is held from the hand-over of the token until the new holder's launch is IN its stream (TeamTokenGuard
+// around enqueueTeam): released in between, the old holder could come back, find the new holder's stream still empty,
+// take the token back and launch beside it -- two engine threads of one self-play process did exactly that.
+// (The holder cannot be destroyed under the wait either: nsg_destroy releases the token under the same mutex.)
 std::mutex gTeamMutex;
 nsg_evaluator* gTeamOwner[64] = {};
-bool acquireTeamToken(nsg_evaluator* ev) {
-    std::lock_guard<std::mutex> lock(gTeamMutex);
-    nsg_evaluator*& owner = gTeamOwner[ev->gpu & 63];
-    if (owner == ev) return true;
-    if (owner != nullptr && hipStreamSynchronize(owner->stream) != hipSuccess) return false;
-    owner = ev;
-    return true;
-}
+struct TeamTokenGuard {
+    std::unique_lock<std::mutex> lock;
+    bool held = false;
+    explicit TeamTokenGuard(nsg_evaluator* ev) : lock(gTeamMutex) {
+        nsg_evaluator*& owner = gTeamOwner[ev->gpu & 63];
+        if (owner != ev && owner != nullptr && hipStreamSynchronize(owner->stream) != hipSuccess) return;
+        owner = ev;
+        held = true;
+    }
+};
 void releaseTeamToken(nsg_evaluator* ev) {
     std::lock_guard<std::mutex> lock(gTeamMutex);
     if (gTeamOwner[ev->gpu & 63] == ev) gTeamOwner[ev->gpu & 63] = nullptr;
@@ -654,8 +659,13 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     static const int teamMax = [] { const char* e = getenv("NSG_TEAM_MAX_BATCH"); const int v = e ? atoi(e) : nsg::kTeamMaxBoards;
                                     return v < 0 ? 0 : (v > nsg::kTeamMaxBoards ? nsg::kTeamMaxBoards : v); }();
     if (ev->teamLayerCount > 0 && ev->teamEnabled && B <= teamMax && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 &&
-        ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && !ev->useTrunkKernel && acquireTeamToken(ev)) {
-        int rc = enqueueTeam(ev, B, s, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
+        ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && !ev->useTrunkKernel) {
+        int rc;
+        {
+            TeamTokenGuard token(ev);
+            if (!token.held) return fail(NSG_E_HIP, "team trunk: waiting for the device's other team launch failed");
+            rc = enqueueTeam(ev, B, s, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
+        }
         if (rc) return rc;
         ev->teamLast = true;
         plan = nsg::ConvPlan{};

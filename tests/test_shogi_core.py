@@ -287,6 +287,28 @@ def test_selfplay_hip_reproducible(nsg, tmp_path):
     assert a["evals_per_sec"] > 0 and 0 <= a["cache_hit_ratio"] < 1
 
 
+@pytest.mark.gpu
+def test_selfplay_team_trunk_two_engine_threads_reproducible(nsg, tmp_path):
+    """Small leaf batches of a 256-channel net run the team trunk (one persistent launch per forward, one such launch
+    per device at a time).  Two engine threads = four evaluators hand the device's token to each other all the time:
+    the run must neither time out (the token is handed over under a lock that is held until the new holder's launch
+    is in its stream -- released earlier, two launches once ran side by side and starved each other) nor depend on
+    the interleaving (every game the same from run to run)."""
+    path = tmp_path / "net.nsgw"
+    nsg.weights.save(str(path), nsg.weights.make_random(2, 256, seed=5, bn="random"))
+    base = ["--executor", "hip", "--weights", str(path), "--precision", "5", "--playouts", "32", "--seed", "11",
+            "--max-games", "8", "--threads", "2", "--games-per-group", "3", "--evaluation-cache-memory-size", "0"]
+    la, lb = tmp_path / "a.log", tmp_path / "b.log"
+    a = json.loads(run("selfplay", *base, "--game-log", la))
+    b = json.loads(run("selfplay", *base, "--game-log", lb))
+    assert a["games_finished"] >= 8 and b["games_finished"] >= 8 and a["avg_batch"] <= 3
+    ga, gb = _game_log(la), _game_log(lb)
+    common = set(ga) & set(gb)
+    assert len(common) >= 6
+    for gid in common:
+        assert ga[gid] == gb[gid], gid
+
+
 def test_selfplay_packed_batches_against_the_sfen_restatement(tmp_path):
     """Host batch packing of the self-play path (selfplay::EvaluationWorker::doTask, SURVEY.md 8a a10):
     for EVERY leaf of every batch, the 1376 bytes the engine packed into that slot of the pinned batch
