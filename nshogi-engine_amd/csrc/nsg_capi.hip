@@ -321,6 +321,7 @@ struct nsg_evaluator {
     int teamDirty[2] = {0, 0}; // boards of each set that do not hold the sentinel
     int teamLayerCount = 0;
     int teamEnabled = 1;
+    hipEvent_t teamDone = nullptr; // behind this evaluator's most recent team launch (the token's next holder waits for it)
     int* teamStatusHost = nullptr; // host-mapped: raised by the kernel when a bounded spin runs out
     int* teamStatusDev = nullptr;
     bool teamLast = false;   // the most recent forward ran the team trunk
@@ -437,13 +438,13 @@ __global__ void delayKernel(unsigned long long ticks) {
 
 // Two team launches on one device could each hold CUs that the other's not-yet-scheduled members need.  One token
 // per device: an evaluator launches a team trunk if it holds the token already (its launches are ordered on its own
-// stream); otherwise it first waits, on the host, until the holder's stream has drained (at most one small-batch
-// forward) and takes the token.  Waiting -- not falling back to the per-layer kernels -- keeps the arithmetic of a
-// batch independent of timing: a self-play engine's two executors then produce the same bits in every run.
-// The mutex is held from the hand-over of the token until the new holder's launch is IN its stream (TeamTokenGuard
-// around enqueueTeam): released in between, the old holder could come back, find the new holder's stream still empty,
-// take the token back and launch beside it -- two engine threads of one self-play process did exactly that.
-// (The holder cannot be destroyed under the wait either: nsg_destroy releases the token under the same mutex.)
+// stream); otherwise its stream first waits -- on the device, hipStreamWaitEvent -- for the event behind the holder's
+// most recent team launch, and it takes the token.  Waiting -- not falling back to the per-layer kernels -- keeps the
+// arithmetic of a batch independent of timing: a self-play engine's two executors then produce the same bits in
+// every run.  The mutex is held from the hand-over of the token until the new holder's launch AND its event are in
+// its stream (TeamTokenGuard around enqueueTeam): released in between, the old holder could come back, find nothing
+// to wait for yet, take the token back and launch beside the new one -- two engine threads of one self-play process
+// did exactly that, and both launches timed out.
 std::mutex gTeamMutex;
 nsg_evaluator* gTeamOwner[64] = {};
 struct TeamTokenGuard {
@@ -451,7 +452,9 @@ struct TeamTokenGuard {
     bool held = false;
     explicit TeamTokenGuard(nsg_evaluator* ev) : lock(gTeamMutex) {
         nsg_evaluator*& owner = gTeamOwner[ev->gpu & 63];
-        if (owner != ev && owner != nullptr && hipStreamSynchronize(owner->stream) != hipSuccess) return;
+        if (owner != ev && owner != nullptr && owner->teamDone &&
+            hipStreamWaitEvent(ev->stream, owner->teamDone, 0) != hipSuccess)
+            return;
         owner = ev;
         held = true;
     }
@@ -480,6 +483,7 @@ int enqueueTeam(nsg_evaluator* ev, int B, hipStream_t s, hipEvent_t trunkBegin, 
         ho.cleanBoards = ev->teamDirty[1 - ev->teamSet];
         NSG_HIP(nsg::launchTeamTrunk((const nsg::TeamLayer*)ev->teamLayers.p, ev->teamLayerCount, B, ho,
                                      ev->teamStatusDev, s));
+        NSG_HIP(hipEventRecord(ev->teamDone, s)); // (under the token's mutex: enqueueForward)
         ev->teamDirty[1 - ev->teamSet] = 0;
         ev->teamDirty[ev->teamSet] = B;
         ev->teamSet = 1 - ev->teamSet;
@@ -663,7 +667,7 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         int rc;
         {
             TeamTokenGuard token(ev);
-            if (!token.held) return fail(NSG_E_HIP, "team trunk: waiting for the device's other team launch failed");
+            if (!token.held) return fail(NSG_E_HIP, "team trunk: hipStreamWaitEvent on the device's other team launch failed");
             rc = enqueueTeam(ev, B, s, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
         }
         if (rc) return rc;
@@ -895,6 +899,7 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
         NSG_HIP(hipMemset(ev->teamSets.p, 0xff, setsBytes));
         ev->teamSet = 0;
         ev->teamDirty[0] = ev->teamDirty[1] = 0;
+        if (!ev->teamDone) NSG_HIP(hipEventCreateWithFlags(&ev->teamDone, hipEventDisableTiming));
         if (!ev->teamStatusHost) {
             NSG_HIP(hipHostMalloc((void**)&ev->teamStatusHost, 64, hipHostMallocMapped));
             *ev->teamStatusHost = 0;
@@ -1029,6 +1034,7 @@ int nsg_destroy(nsg_evaluator* ev) {
     if (ev->teamLayerCount) nsg::teamTrunkDumpStamps();
 #endif
     if (ev->teamStatusHost) (void)hipHostFree(ev->teamStatusHost);
+    if (ev->teamDone) (void)hipEventDestroy(ev->teamDone); // (a stream that waits for it keeps what it needs)
     for (hipEvent_t e : ev->ev) (void)hipEventDestroy(e);
     for (auto cs : ev->chainStream)
         if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
