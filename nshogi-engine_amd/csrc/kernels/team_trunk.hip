@@ -52,6 +52,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -428,14 +429,18 @@ hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, 
     if (nLayers < 3 || boards < 1 || boards > kTeamMaxBoards || !handoff.set || !handoff.other ||
         handoff.imageStride < (size_t)boards * 81 * 1024 || handoff.imageStride < (size_t)handoff.cleanBoards * 81 * 1024)
         return hipErrorInvalidValue;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)teamTrunkKernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)teamTrunkKernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)teamTrunkKernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)teamTrunkKernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        if (e != hipSuccess) return e;
-        attr = true;
+    // (the attribute belongs to a function ON a device: one process may drive several -- selfplay --num-gpus)
+    static std::atomic<unsigned long long> attrDevMask{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (!(attrDevMask.load() & (1ull << (dev & 63)))) {
+        const void* kernels[] = {(const void*)teamTrunkKernel<1>, (const void*)teamTrunkKernel<2>,
+                                 (const void*)teamTrunkKernel<3>, (const void*)teamTrunkKernel<6>};
+        for (const void* k : kernels) {
+            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+            if (e != hipSuccess) return e;
+        }
+        attrDevMask.fetch_or(1ull << (dev & 63));
     }
     if (teamMembers(boards) == 96)
         hipLaunchKernelGGL(teamTrunkKernel<1>, dim3(boards * 96), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
