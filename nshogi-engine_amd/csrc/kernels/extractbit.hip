@@ -13,21 +13,11 @@
 // 256-thread workgroup stages a run of bitboards in LDS with one coalesced
 // 16-byte load per lane and then streams the planes out as fully coalesced
 // 16-byte stores; the kernel is HBM-write bound (29 240 B per position).
+#include "bitboard.h"
 #include "kernels.h"
 
 namespace nsg {
 namespace {
-
-__device__ __forceinline__ uint32_t selectBit(uint64_t lo, uint64_t hi, int bit) {
-    const uint32_t hi32 = (uint32_t)hi;
-    const int rotate = (hi32 >> 24) & 1;
-    const uint32_t value = (uint32_t)(hi >> 32);
-    const int target = rotate ? 80 - bit : bit;
-    const bool useHi = target >= 63;
-    const uint64_t word = useHi ? hi : lo;
-    const int shift = useHi ? target - 63 : target;
-    return ((word >> shift) & 1ULL) ? value : 0u;
-}
 
 constexpr int kThreads = 256;
 

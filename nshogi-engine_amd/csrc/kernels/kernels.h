@@ -149,6 +149,10 @@ struct TeamHandoff {
     unsigned char* other;
     size_t imageStride;
     int cleanBoards;
+    // layer 0's input as the evaluator received it: [boards][bitChannels] 128-bit feature bitboards (the planes are
+    // decoded while the first layer stages them: no plane buffer, no extraction launch); null: TeamLayer::x of layer 0
+    const void* bits;
+    int bitChannels;
 };
 bool teamTrunkSupports(int channels, int stemKdim, int boards);
 int teamMembers(int boards); // workgroups per board of a launch of `boards` boards

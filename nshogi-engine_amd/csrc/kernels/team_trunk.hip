@@ -48,6 +48,7 @@
 // Arithmetic: kF16x3 (split f16 hi/lo, three f16 MFMAs per MAC, f32 accumulate) on the kF16x3 records the evaluator
 // keeps for batches without an MX plan -- a channel subset can be written without its neighbours (the MX formats
 // share one exponent per 32 channels across FOUR members' outputs).
+#include "bitboard.h"
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -238,7 +239,34 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         TEAM_STAMP(1)
         // ---- this wave's chunk of the board -> its LDS image; a piece is there when neither of its halves is the
         // sentinel (layer 0 reads the planes of the launch before this one: there at the first request)
-        if (wave < nkc) {
+        if (wave < nkc && !fromImage && ho.bits) {
+            // layer 0 straight from the feature bitboards (bitboard.h): this lane's LDS piece = channels 32 wave +
+            // 8 (2 gq + jp) .. + 7 of its rows; the f16 hi / lo split of extractAct<kF16x3>, bit for bit
+            typedef unsigned long long u64_;
+            const int c0 = wave * 32 + (2 * stGq + stJp) * 8;
+            u32x4 bb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                bb[i] = c0 + i < ho.bitChannels
+                            ? asGlobal<u32x4>(ho.bits)[(size_t)team * ho.bitChannels + c0 + i]
+                            : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < kImgItems; ++k) {
+                const int row = (item0 + k) * 16 + li;
+                if (row < rowLo || row > rowHi) continue;
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const float a = __uint_as_float(selectBit(((u64_)bb[i].y << 32) | bb[i].x, ((u64_)bb[i].w << 32) | bb[i].z, row));
+                    const float b = __uint_as_float(selectBit(((u64_)bb[i + 1].y << 32) | bb[i + 1].x,
+                                                              ((u64_)bb[i + 1].w << 32) | bb[i + 1].z, row));
+                    splitPair(a, b, -65000.f, hi[i / 2], lo[i / 2]);
+                }
+                unsigned char* d = img + imgDst + entry16(row);
+                *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<u32x4*>(d + 4 * kPlane) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            }
+        } else if (wave < nkc) {
             // item k of a lane = two 16-byte pieces of row 16 k + lane % 16 that make LDS piece 2 gq + jp (hi) and
             // its lo twin: from an image the two members' [hi4 | lo4] (32 bytes apart), from the evaluator's layout
             // (layer 0) the hi piece and the lo piece themselves (64 bytes apart)

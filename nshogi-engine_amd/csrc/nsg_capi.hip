@@ -468,11 +468,7 @@ void releaseTeamToken(nsg_evaluator* ev) {
 int enqueueTeam(nsg_evaluator* ev, int B, hipStream_t s, hipEvent_t trunkBegin, hipEvent_t trunkEnd) {
     const int prec = nsg::kF16x3;
     ev->lastTrunkPrec = prec;
-    {
-        Range r("nsg.planes");
-        NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, B, ev->numChannels, ev->cpad, prec, s));
-    }
-    {
+    {   // (the feature bitboards are decoded by the first layer of the team launch itself)
         Range r("nsg.trunk");
         if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
         nsg::TeamHandoff ho;
@@ -481,6 +477,8 @@ int enqueueTeam(nsg_evaluator* ev, int B, hipStream_t s, hipEvent_t trunkBegin, 
         ho.set = (unsigned char*)ev->teamSets.p + (size_t)ev->teamSet * setBytes;
         ho.other = (unsigned char*)ev->teamSets.p + (size_t)(1 - ev->teamSet) * setBytes;
         ho.cleanBoards = ev->teamDirty[1 - ev->teamSet];
+        ho.bits = ev->input.p;
+        ho.bitChannels = ev->numChannels;
         NSG_HIP(nsg::launchTeamTrunk((const nsg::TeamLayer*)ev->teamLayers.p, ev->teamLayerCount, B, ho,
                                      ev->teamStatusDev, s));
         NSG_HIP(hipEventRecord(ev->teamDone, s)); // (under the token's mutex: enqueueForward)
