@@ -10,8 +10,10 @@
 // 18 KiB = 72 registers, requested as soon as the layer before has stored its output.  Per layer a member loads
 // its input (each wave its own chunk of the rows it needs, into a wave-private LDS image: no workgroup barrier),
 // runs 27 MFMAs per wave and row fragment, adds the eight K parts through LDS, finishes its row fragments (bias,
-// residual, ReLU, f16 hi/lo split) and hands its output to the team.  (A 32-member team is the blocks of one
-// residue mod 8: they share an XCD, and its L2 the weights, under the observed round-robin placement -- speed only.)
+// residual, ReLU, f16 hi/lo split) and hands its output to the team.  (Block b computes weight fragment b % 16 -- every
+// team size is a multiple of 16 -- so under the observed round-robin placement an XCD's L2 holds the records of two
+// fragments for every board: one copy of the records leaves memory per launch.  Teams that each lived on one XCD
+// fetched them eight times over, 774 MB per launch at eight boards: profiles/r03/README.md.  Speed only.)
 //
 // Hand-off: the payload is its own flag.  The layers but the last write into four rotating images (`TeamHandoff::
 // set`, [boards][81 rows][1024 B]; layer l writes image l % 4) that hold the SENTINEL -- all bits set -- where
@@ -136,8 +138,10 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kMembers = 16 * (6 / FR);
     constexpr int kSub = FR > 3 ? 3 : FR, kSubs = FR / kSub; // row fragments per fragment-read step, steps per tap
-    const int team = FR == 3 ? (int)(blockIdx.x & 7) : (int)(blockIdx.x / kMembers);
-    const int rank = FR == 3 ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x % kMembers);
+    // (kMembers is a multiple of 16: block b computes weight fragment b % 16, and under the observed round-robin
+    // placement XCD b % 8 -- an XCD's L2 holds the records of two fragments, for every board)
+    const int team = (int)(blockIdx.x / kMembers);
+    const int rank = (int)(blockIdx.x % kMembers);
     if (team >= boards || rank >= kMembers || team >= kTeamMaxBoards) return;
     const int j = rank & 15, h = rank >> 4; // weight fragment (16 output channels), row group (half or single fragment)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -480,7 +484,7 @@ hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, 
         hipLaunchKernelGGL(teamTrunkKernel<6>, dim3(boards * 16), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
                            handoff, status);
     else
-        hipLaunchKernelGGL(teamTrunkKernel<3>, dim3(8 * 32), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
+        hipLaunchKernelGGL(teamTrunkKernel<3>, dim3(boards * 32), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
                            handoff, status);
     return hipGetLastError();
 }
