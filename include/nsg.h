@@ -206,7 +206,9 @@ int nsg_download_trunk(nsg_evaluator* ev, size_t batch_size, float* dst);
 /* Debug read-back of the trunk INPUT exactly as the last forward's plane
  * expansion wrote it: raw bytes, [batch][81][padded channels] in the trunk
  * precision's element layout; *row_bytes receives the
- * bytes per (board, square).  capacity is checked. */
+ * bytes per (board, square).  capacity is checked.  NSG_E_INVALID after a
+ * forward of at most sixteen boards of a 256-channel net (the team trunk
+ * decodes the bitboards inside its first layer: no plane buffer exists). */
 int nsg_download_planes_raw(nsg_evaluator* ev, size_t batch_size, void* dst,
                             size_t capacity, size_t* row_bytes);
 

@@ -1459,6 +1459,9 @@ int nsg_download_planes_raw(nsg_evaluator* ev, size_t batch_size, void* dst, siz
     int rc = checkCompute(ev, batch_size);
     if (rc) return rc;
     if (!ev->trunkOut) return fail(NSG_E_INVALID, "no forward has run yet");
+    if (ev->teamLast)
+        return fail(NSG_E_INVALID, "the last forward ran the team trunk, which decodes the bitboards inside its first layer: "
+                                   "there is no plane buffer for it (NSG_TEAM_TRUNK=0 keeps the per-layer kernels)");
     if (!dst || !row_bytes) return fail(NSG_E_INVALID, "null argument");
     const size_t es = nsg::elemSize(ev->lastTrunkPrec);
     const size_t rb = (size_t)ev->cpad * es;

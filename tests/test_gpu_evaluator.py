@@ -945,3 +945,16 @@ def test_team_trunk_two_evaluators_share_a_device(nsg, oracle):
         np.testing.assert_array_equal(pa[0], pb[0])
         np.testing.assert_array_equal(pa[1], pb[1])
         assert a.last_plan()["waves_per_group"] == 8 and b.last_plan()["waves_per_group"] == 8
+
+
+def test_planes_download_after_a_team_forward_fails_loudly(nsg):
+    """The team trunk decodes the feature bitboards inside its first layer: after such a forward there is no plane
+    buffer to read back, and the debug read-back says so instead of returning the planes of an earlier batch."""
+    ev, _ = make(nsg, 1, 256, 32, precision="f16m6", seed=4)
+    bb = nsg.synth.random_batch(32, 86, seed=20)
+    ev.compute_blocking(bb)  # 32 boards: per-layer kernels, planes in memory
+    assert ev.download_planes_raw(32).shape[0] == 32
+    ev.compute_blocking(bb[:4])
+    assert ev.last_plan()["k_split"] == 8  # the team trunk
+    with pytest.raises(nsg.NsgError, match="team trunk"):
+        ev.download_planes_raw(4)
