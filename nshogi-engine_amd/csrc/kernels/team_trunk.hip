@@ -208,6 +208,22 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         }
     };
 
+    // Diagnostic build -DTEAM_JITTER (never shipped): every member idles a pseudo-random time (up to ~30 us, longer
+    // than a layer) at the points that matter for the hand-off argument at the head of the file -- before its tile
+    // requests, before its output stores, before it restores the sentinel -- so that members drift layers apart as
+    // far as the protocol lets them.  tests/test_gpu_evaluator.py::test_team_trunk_handoff_images_across_launches
+    // passes on that build (profiles/r03/README.md).
+#ifdef TEAM_JITTER
+#define TEAM_IDLE(POINT)                                                                                        \
+    {                                                                                                           \
+        unsigned hsh = (blockIdx.x * 2654435761u) ^ ((unsigned)l * 40503u) ^ ((POINT) * 2246822519u);            \
+        hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;                                                 \
+        if ((hsh & 3u) == 0)                                                                                    \
+            for (unsigned i = 0; i < (hsh >> 27); ++i) __builtin_amdgcn_s_sleep(32);                            \
+    }
+#else
+#define TEAM_IDLE(POINT)
+#endif
 #ifdef TEAM_STAMPS
 #define TEAM_STAMP(I) if (blockIdx.x == 0 && tid == 0 && l >= 2 && l < 34) gTeamStamps[(l - 2) * 8 + (I)] = __builtin_amdgcn_s_memtime();
 #else
@@ -241,6 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
             if (resPtr && mOut < 81) resV = loadAgent16(oldBuf, rowImg);
         }
         TEAM_STAMP(1)
+        TEAM_IDLE(1)
         // ---- this wave's chunk of the board -> its LDS image; a piece is there when neither of its halves is the
         // sentinel (layer 0 reads the planes of the launch before this one: there at the first request)
         if (wave < nkc && !fromImage && ho.bits) {
@@ -386,6 +403,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += (float)rh[r] + (float)rl[r];
                 }
+                TEAM_IDLE(2)
                 const float floorV = L.relu ? 0.f : -65000.f;
                 unsigned h01, l01, h23, l23;
                 splitPair(v[0], v[1], floorV, h01, l01);
@@ -398,6 +416,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                 }
                 // behind the barrier above = C(n, l), every wave of the member has its input: the sentinel goes
                 // back over this member's output of layer l - 2 (see the head of the file)
+                TEAM_IDLE(3)
                 if (oldPtr) storeAgent16(oldBuf, rowImg, u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
             }
         }
