@@ -81,50 +81,59 @@ def _physical_cores_available():
     return max(1, len(seen))
 
 
-def cpu_baseline(seconds=8.0, all_cores_seconds=6.0, max_threads=16):
-    """The reference's EXECUTOR=random CPU path (src/infer/random.cc:28-42 driven
-    like src/bench/batchsize.cc) via the oracle restatement ("port"), batch 512, bounded to
-    ~`seconds` of CPU work: (i) one core -- what one reference evaluation thread does;
-    (ii) SURVEY.md 8d (ii): one Random + buffer pair per thread on T threads at once (T = the
-    physical cores this process may use, capped at `max_threads`: a one-GPU box's CPU share is 16)."""
+def cpu_baseline(nsg, seconds=8.0, pool_seconds=5.0, share_threads=16):
+    """The reference's EXECUTOR=random CPU path (src/infer/random.cc:28-42 driven like src/bench/batchsize.cc):
+    the PRODUCT's restatement of it -- nsg_cpu_executor (csrc/cpu_executor.cc), built with the reference's own release
+    flags (Makefile:30-32 + the AVX2 set) -- at batch 512, bounded to ~`seconds` of CPU work per leg:
+    (i) one core: what one reference evaluation thread does; (ii) SURVEY.md 8d (ii): one executor + output buffers
+    per thread, on the 16 threads that are a one-GPU box's CPU share, and on every physical core this process may
+    run on.  ("port": the reference itself cannot be built here -- libnshogi is absent.)"""
     import threading
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib
-    o = oracle_lib.load()
-    st = o.mt(0)
-    o.random_compute(st, 512)  # warm-up
+    B = 512
+    model = _cpu_model()
+
+    def one(seed):
+        return (nsg.CpuExecutor("random", seed=seed), np.empty((B, 2187), np.float32), np.empty(B, np.float32),
+                np.empty(B, np.float32))
+
+    ex, pol, win, drw = one(0)
+    ex.compute_blocking(B, policy=pol, win=win, draw=drw)  # warm-up
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        o.random_compute(st, 512)
-        n += 512
+        ex.compute_blocking(B, policy=pol, win=win, draw=drw)
+        n += B
     dt = time.perf_counter() - t0
-    model = _cpu_model()
+    built = "nsg_cpu_executor (the product's infer::Random, -O3 -ffast-math + the reference's release flags)"
     out = {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-           "sample": f"infer::Random(0) restatement, batch 512, {n} positions in {dt:.1f} s on 1 of "
-                     f"{os.cpu_count()} host cores ({model})"}
+           "sample": f"{built}, seed 0, batch {B}, {n} positions in {dt:.1f} s on 1 of {os.cpu_count()} host threads ({model})"}
     phys = _physical_cores_available()
-    T = max(1, min(phys, max_threads))
-    counts = [0] * T
-    stop = time.perf_counter() + all_cores_seconds
 
-    def work(i):  # ctypes releases the GIL inside the oracle call: the threads run in parallel
-        mine = o.mt(i)
-        while time.perf_counter() < stop:
-            o.random_compute(mine, 512)
-            counts[i] += 512
+    def pool(T):
+        counts = [0] * T
+        sets = [one(i) for i in range(T)]
+        stop = time.perf_counter() + pool_seconds
 
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    out["all_cores"] = {"value": sum(counts) / dt, "unit": "evals/s", "cores": T, "kind": "port",
-                        "physical_cores_available": phys, "host_threads_total": os.cpu_count(),
-                        "sample": f"{T} threads, one infer::Random(seed i) restatement + output buffers each, batch 512, "
-                                  f"{sum(counts)} positions in {dt:.1f} s ({model}); T = physical cores available to this "
-                                  f"process capped at {max_threads} (the CPU share of a one-GPU box)"}
+        def work(i):  # ctypes releases the GIL inside the call: the threads run in parallel
+            e, p, w, d = sets[i]
+            while time.perf_counter() < stop:
+                e.compute_blocking(B, policy=p, win=w, draw=d)
+                counts[i] += B
+
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        return {"value": sum(counts) / dt, "unit": "evals/s", "cores": T, "kind": "port",
+                "sample": f"{T} threads, one {built} (seed i) + output buffers each, batch {B}, {sum(counts)} positions "
+                          f"in {dt:.1f} s ({model})"}
+
+    out["gpu_share_16_threads"] = pool(max(1, min(phys, share_threads)))
+    out["all_cores"] = pool(phys)
+    out["all_cores"]["physical_cores_available"] = phys
+    out["all_cores"]["host_threads_total"] = os.cpu_count()
     return out
 
 
@@ -134,7 +143,7 @@ def pmc_summary(args, B):
     this run: PMC collection needs its own rocprofv3 passes; the bench line names the file."""
     if args.net != "20x256" or B != 512:
         return None, None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         rel = os.path.join("profiles", rnd, f"pmc_{args.precision}_summary.json")
         try:
             return json.load(open(os.path.join(ROOT, rel))), rel
@@ -166,29 +175,32 @@ def conv_mfma_busy(d):
     return sum(v) / len(v) if v else None
 
 
-def extract_traffic(B):
+def extract_traffic(B, kernel="extractNCHW"):
     """HBM bytes per extractNCHW launch from the committed PMC passes (scripts/pmc_extract.sh), newest round
     first: (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per the guide's gfx950 correction."""
     if B != 512:
         return None, None
-    for rnd in ("r03",):
+    for rnd in ("r04", "r03"):
         rel = os.path.join("profiles", rnd, "pmc_extract_summary.json")
         try:
             d = json.load(open(os.path.join(ROOT, rel)))
         except (OSError, ValueError):
             continue
         for name, c in d.items():
-            if "extractNCHW" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, rel
     return None, None
 
 
-def extract_roofline(nsg, bb, B):
-    """Second roofline entry: the plane-expansion kernel alone, HBM-bound.
-    Algorithmic bytes per position = 1376 read + 27 864 written.  Timed live with HIP events on
-    the stream the kernel is launched on (torch's current stream, handed to nsg_extract_bits)."""
+def extract_roofline(nsg, ev, bb, B, precision):
+    """Second roofline entry: plane expansion, HBM-bound.  The kernel the forward pass RUNS
+    (extractAct<precision>: the bit selection of extractbit.cu:19-37 written straight into the trunk's input layout,
+    [81][padded channels] rows in the evaluator's element format) is timed on the evaluator's own stream
+    (nsg_time_planes, HIP events) and is the entry's achieved / frac; the reference-layout kernel behind
+    nsg_extract_bits (fp32 NCHW, the reference's K1; not on the forward path) is reported beside it."""
     import torch
     C = 86
+    ms_act, bytes_act = ev.time_planes(B, 200)
     src = torch.from_numpy(bb.view(np.int64).copy()).cuda()
     dst = torch.empty(B * C * 81, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -206,17 +218,57 @@ def extract_roofline(nsg, bb, B):
         torch.cuda.synchronize()
         out[name] = e0.elapsed_time(e1) / iters
     nbytes = B * (1376 + 27864)
-    ms = out["NCHW"]
-    traffic, traffic_file = extract_traffic(B)
-    return {"bound": "hbm", "achieved": nbytes / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
-            "frac": nbytes / ms / 1e6 / 8000.0, "traffic": traffic,
+    kname = {"f16m6": "extractActM6", "f16m8": "extractActM8"}.get(precision, "extractAct")
+    traffic, traffic_file = extract_traffic(B, kname)
+    t2, t2_file = extract_traffic(B)
+    return {"bound": "hbm", "achieved": bytes_act / ms_act / 1e6, "peak": 8000.0, "unit": "GB/s",
+            "frac": bytes_act / ms_act / 1e6 / 8000.0, "traffic": traffic,
             "traffic_source": (f"{traffic_file} (committed rocprofv3 --pmc passes of this kernel at this batch, NOT "
                                f"measured by this run)" if traffic_file else None),
-            "kernel": "extractNCHW (nsg_extract_bits, channels first; the reference's K1)",
-            "avg_launch_ms": ms, "launches_timed": 200, "algorithmic_bytes_per_launch": nbytes,
-            "nhwc_avg_launch_ms": out["NHWC"], "nhwc_GB_per_s": nbytes / out["NHWC"] / 1e6,
-            "note": "one launch moves 15 MB at batch 512: launch + first-byte latency, not bandwidth, "
-                    "sets its time (profiles/r02/extract_roofline.json has the batch sweep)"}
+            "kernel": f"{kname} (the plane expansion on the forward path: bitboards -> [81][128] trunk-input rows, "
+                      f"{precision} element format, 4 B per channel)",
+            "avg_launch_ms": ms_act, "launches_timed": 200, "algorithmic_bytes_per_launch": bytes_act,
+            "reference_layout_kernel": {
+                "kernel": "extractNCHW (nsg_extract_bits, fp32 channels first: the reference's K1, extractbit.cu:15-39; "
+                          "not on the forward path)",
+                "achieved": nbytes / out["NCHW"] / 1e6, "frac": nbytes / out["NCHW"] / 1e6 / 8000.0, "unit": "GB/s",
+                "avg_launch_ms": out["NCHW"], "algorithmic_bytes_per_launch": nbytes, "traffic": t2,
+                "traffic_source": t2_file, "nhwc_avg_launch_ms": out["NHWC"], "nhwc_GB_per_s": nbytes / out["NHWC"] / 1e6},
+            "note": "one launch moves 15-22 MB at batch 512: launch + first-byte latency, not bandwidth, sets its time "
+                    "(profiles/r02/extract_roofline.json has the batch sweep); 0.5 % of a forward"}
+
+
+def config_leg(nsg, gpu, net, batch, precision, seconds=1.5):
+    """One more BASELINE config on this GPU: device-resident evals/s, the trunk conv's average launch time (HIP
+    events on the evaluator's stream) and the fraction of the f16/bf16 MFMA peak, for `net` at `batch`."""
+    import torch
+    blocks, channels = (int(x) for x in net.split("x"))
+    ev = nsg.Evaluator(gpu, batch, 86, precision=precision)
+    t0 = time.perf_counter()
+    ev.load_memory(nsg.weights.to_blob(nsg.weights.make_random(blocks, channels, seed=0, bn="identity")))
+    load_s = time.perf_counter() - t0
+    ev.upload_features(nsg.positions.startpos_batch(batch))
+    for _ in range(3):
+        ev.forward_resident(batch)
+    torch.cuda.synchronize()
+    ev.profile_enable(True)
+    ev.profile_read()
+    rate, n, took = held_rate(lambda: ev.forward_resident(batch), batch, torch.cuda.synchronize, seconds)
+    prof = ev.profile_read()
+    ev.profile_enable(False)
+    info, plan = ev.info(), ev.last_plan()
+    conv_ms = prof["trunk_ms_total"] / max(prof["trunk_launches"], 1)
+    one_launch = prof["trunk_launches"] == prof["forwards"]  # (team trunk / persistent trunk: the events bracket ONE launch)
+    conv_flops = info["trunk_conv_flops_per_position"] * batch * (2 * blocks if one_launch else 1)
+    peak = PEAK_TFLOPS[precision]
+    ev.close()
+    return {"net": net, "batch": batch, "precision": precision, "trunk_precision": plan["trunk_precision"],
+            "evals_per_sec": rate, "whole_net_frac_of_peak": rate * info["flops_per_position"] / 1e12 / peak,
+            "conv_avg_launch_ms": conv_ms, "conv_launches_timed": prof["trunk_launches"],
+            "conv_frac_of_peak": conv_flops / (conv_ms * 1e-3) / 1e12 / peak if conv_ms > 0 else None,
+            "conv_timing_covers": "the one persistent launch of all 3x3 layers" if one_launch else "one F->F 3x3 conv launch",
+            "plan": plan, "forwards_timed": n, "seconds": took, "load_seconds_incl_weight_packing": load_s,
+            "positions": "startpos"}
 
 
 def held_rate(fn, B, sync, seconds):
@@ -417,6 +469,10 @@ def main():
     # threads that run the df-pn mate solver of judge (100 000 nodes, worker.cc:516) off the search path
     ap.add_argument("--selfplay-solver-threads", type=int, default=4)
     ap.add_argument("--selfplay-games-per-group", type=int, default=128)
+    ap.add_argument("--selfplay-deterministic-seconds", type=float, default=20.0,
+                    help="length of the second self-play leg in the shape whose move digests reproduce bit for bit "
+                         "(one search worker, no solver pool: north_star's fixed-seed determinism); 0 disables it")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the by_config legs (configs[1], configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-sample", action="store_true",
                     help="no rocm-smi child processes during the sustained leg (under rocprofv3 the box refuses a "
@@ -560,6 +616,12 @@ def main():
         mine = selfplay_leg(wpath, local_rank, args.selfplay_seconds, args.selfplay_threads, args.precision,
                             games_per_group=args.selfplay_games_per_group, workers=args.selfplay_workers,
                             solvers=args.selfplay_solver_threads)
+        det = None
+        if args.selfplay_deterministic_seconds > 0 and world == 1:
+            # the same leg in the shape whose per-game move sequences are a function of the seed alone
+            # (selfplay.h: one search worker, no solver pool): what that guarantee costs in throughput
+            det = selfplay_leg(wpath, local_rank, args.selfplay_deterministic_seconds, args.selfplay_threads,
+                               args.precision, games_per_group=args.selfplay_games_per_group, workers=1, solvers=0)
         try:
             os.remove(wpath)
         except OSError:
@@ -589,6 +651,20 @@ def main():
                            "blocked in Infer::await, host_ms_per_batch = its work between two batches, "
                            "batches_found_finished = share of batches that had already finished when the engine came "
                            "back for them (0: the executor never waited for the host)")
+            sp["determinism"] = ("this shape (%s search workers, %s solver threads) is the throughput shape: batch "
+                                 "composition depends on thread timing, so per-game move digests do NOT reproduce from "
+                                 "the seed; the deterministic_shape leg (1 worker, no solver pool) is the one that "
+                                 "satisfies north_star's 'bit-identical under a fixed RNG seed' "
+                                 "(tests: test_selfplay_hip_reproducible, test_config3_selfplay_256_games_800_playouts)"
+                                 % (mine.get("workers"), mine.get("solver_threads")))
+            if det is not None and "error" not in det:
+                sp["deterministic_shape"] = {k: det[k] for k in ("games_per_sec", "games_per_sec_window", "evals_per_sec",
+                                                                 "playouts_per_sec", "avg_batch", "seconds", "digest",
+                                                                 "games_finished", "await_ms_per_batch", "host_ms_per_batch")
+                                             if k in det}
+                sp["deterministic_shape"].update(workers_per_thread=1, solver_threads=0)
+            elif det is not None:
+                sp["deterministic_shape"] = det
         barrier()
         ev = None
 
@@ -712,17 +788,23 @@ def main():
                 big = nsg.Evaluator(local_rank, 1024, 86, precision=args.precision)
                 big.load_memory(blob)
                 big.upload_features(nsg.positions.startpos_batch(1024))
-                by_batch = {}
-                for nb in (1, 8, 32, 64, 128, 256, 1024):  # 128 = the engine's default BatchSize (context.h:79)
+                by_batch, prec_by_batch = {}, {}
+                for nb in (1, 8, 16, 17, 32, 64, 128, 256, 1024):  # 128 = the engine's default BatchSize (context.h:79)
                     rate, n, took = held_rate(lambda: big.forward_resident(nb), nb, torch.cuda.synchronize, 1.0)
                     by_batch[str(nb)] = rate
+                    prec_by_batch[str(nb)] = big.last_plan()["trunk_precision"]
                 by_batch["512"] = value
+                prec_by_batch["512"] = args.precision
                 out["evals_per_sec_by_batch"] = by_batch
+                # the arithmetic each batch size ran its trunk in: up to sixteen boards take the team trunk (f16x3: three
+                # f16 MFMAs per MAC on 4-byte-per-weight hi/lo records), the rest the line's precision
+                out["trunk_precision_by_batch"] = prec_by_batch
                 # ... and as a fraction of the MFMA roofline (north_star: "as absolute numbers and as fraction
                 # of the MFMA roofline"): evals/s x algorithmic flops per position / the f16 dense peak
                 out["frac_of_mfma_roofline_by_batch"] = {k: v * flops_pos / 1e12 / peak for k, v in by_batch.items()}
                 # small batches are bound by the WEIGHT stream, not by MFMA: every forward reads every packed trunk
-                # record once (4 bytes per weight as packed: f16 + two e2m3 copies + exponents / padding), so the roof
+                # record once (4 bytes per weight as packed -- MX plans: f16 + two e2m3 copies + exponents / padding; the
+                # team trunk's f16x3 records: f16 hi + f16 lo -- the same 4 bytes in either format), so the roof
                 # is forwards/s x packed bytes against the 8 TB/s of HBM (the weights sit in the 256 MB Infinity Cache
                 # between forwards; HBM is the conservative roof)
                 wbytes = 4.0 * 9 * (128 * channels + 2 * blocks * channels * channels)
@@ -730,13 +812,26 @@ def main():
                 out["frac_of_weight_bw_roofline_by_batch"] = {k: (v / int(k)) * wbytes / 8e12 for k, v in by_batch.items()
                                                               if int(k) <= 64}
                 big.close()
-            out["roofline_extract"] = extract_roofline(nsg, bb, B)
+            # ---- the other BASELINE configs on this GPU with this round's kernels
+            if B == 512 and args.net == "20x256" and not args.no_other_configs:
+                out["by_config"] = {
+                    "configs[1] 10x192 batch 64": config_leg(nsg, local_rank, "10x192", 64, args.precision),
+                    "configs[4] 40x384 bf16 batch 1024": config_leg(nsg, local_rank, "40x384", 1024, "bf16"),
+                    "configs[4] 40x384 batch 1024 at the 1e-3 parity arithmetic": config_leg(nsg, local_rank, "40x384", 1024,
+                                                                                       args.precision)}
+            rev = nsg.Evaluator(local_rank, B, 86, precision=args.precision)
+            rev.load_memory(blob)
+            rev.upload_features(bb)
+            out["roofline_extract"] = extract_roofline(nsg, rev, bb, B, args.precision)
+            rev.close()
         if not args.no_host_path and world == 1:
             out["other_precisions_evals_per_sec"] = {
                 p: quick_rate(nsg, local_rank, blob, bb, B, p) for p in ("fp32", "f16x3", "f16m8", "f16m6", "fp16", "bf16")
                 if p != args.precision}
-        if not args.no_cpu_baseline:  # rank 0 only; at N > 1 the other ranks idle at the barrier below meanwhile
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu_baseline and world == 1:
+            # N = 1 only (the measurement contract): at N > 1 the other ranks would spin in a collective on the host
+            # cores this leg measures
+            out["cpu_baseline"] = cpu_baseline(nsg)
             if os.path.exists(SELFPLAY_BIN):
                 out["cpu_baseline"]["selfplay_random_1thread_100playouts"] = selfplay_cpu_baseline()
     if distributed:

@@ -212,6 +212,13 @@ int nsg_download_trunk(nsg_evaluator* ev, size_t batch_size, float* dst);
 int nsg_download_planes_raw(nsg_evaluator* ev, size_t batch_size, void* dst,
                             size_t capacity, size_t* row_bytes);
 
+/* HIP-event timing of the plane-expansion kernel the forward pass actually runs (the bit selection of
+ * cuda::extractBits, src/cuda/extractbit.cu:15-39, written straight into the trunk's input layout in the
+ * evaluator's arithmetic): `iterations` launches on the resident input, on the evaluator's stream.
+ * *bytes_per_launch = algorithmic bytes: batch x (num_channels x 16 read + 81 x padded channels x element size
+ * written).  (Batches that run the team trunk decode the bitboards inside its first layer instead.) */
+int nsg_time_planes(nsg_evaluator* ev, size_t batch_size, int iterations, float* avg_ms, double* bytes_per_launch);
+
 /* HIP-event timing of the dominant kernel (the F->F 3x3 residual
  * convolution) on the evaluator's own stream.  While enabled, every forward
  * brackets its run of trunk-conv launches with two events; nsg_profile_read
@@ -259,6 +266,17 @@ int nsg_get_info(nsg_evaluator* ev, nsg_info* info);
  * its phases in roctx ranges nsg.h2d / nsg.planes / nsg.trunk / nsg.heads / nsg.d2h
  * for `rocprofv3 --marker-trace`. */
 int nsg_get_stats(nsg_evaluator* ev, uint64_t* batches, uint64_t* positions);
+
+/* The team trunk (batches of at most sixteen boards of a 256- or 192-channel net: every 3x3 layer in one
+ * persistent launch whose workgroups hand activations to each other) needs all its workgroups resident at once.
+ * It is taken only when boards x workgroups-per-board fits the device's compute units, by one process per device
+ * (an advisory file lock named after the PCI bus id) and one launch per device at a time inside that process.
+ * Should a launch still wait in vain (~1 s), the batch is re-run on the per-layer kernels before nsg_await or any
+ * other synchronising entry returns -- the call succeeds -- and the evaluator keeps to those kernels afterwards.
+ * *enabled: 1 the team path is in use, 0 it is off (no layer list, NSG_TEAM_TRUNK=0, or after a fallback),
+ * -1 another process holds the device's token; *members_last: workgroups per board of the most recent team
+ * launch; *fallbacks: launches that gave up and were re-run. */
+int nsg_get_team_stats(nsg_evaluator* ev, int* enabled, int* members_last, uint64_t* fallbacks);
 
 /* Launch plan of the most recent forward pass (tests and tuning): boards per
  * workgroup, 16-channel fragments per wave, waves per workgroup, and the number

@@ -94,6 +94,7 @@ def load_library():
     lib.nsg_download_trunk.argtypes = [vp, sz, vp]
     lib.nsg_download_planes_raw.argtypes = [vp, sz, vp, sz, ctypes.POINTER(ctypes.c_size_t)]
     lib.nsg_profile_enable.argtypes = [vp, i]
+    lib.nsg_time_planes.argtypes = [vp, sz, i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
     lib.nsg_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_uint64),
                                      ctypes.POINTER(ctypes.c_double),
@@ -102,6 +103,7 @@ def load_library():
     lib.nsg_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     ip = ctypes.POINTER(ctypes.c_int)
     lib.nsg_get_last_plan.argtypes = [vp, ip, ip, ip, ip]
+    lib.nsg_get_team_stats.argtypes = [vp, ip, ip, ctypes.POINTER(ctypes.c_uint64)]
     lib.nsg_get_last_trunk_precision.argtypes = [vp, ip]
     lib.nsg_get_last_split.argtypes = [vp, ip, ip]
     lib.nsg_get_last_slab_split.argtypes = [vp, ip]
@@ -278,6 +280,12 @@ class Evaluator:
         _check(self._lib.nsg_download_planes_raw(self._h, int(batch_size), _ptr(buf), cap, ctypes.byref(rb)))
         return buf[: int(batch_size) * NUM_SQUARES * rb.value].reshape(int(batch_size), NUM_SQUARES, rb.value)
 
+    def time_planes(self, batch_size, iterations=200):
+        """nsg_time_planes: (average ms per launch, algorithmic bytes per launch) of the on-path plane expansion."""
+        ms, nbytes = ctypes.c_float(), ctypes.c_double()
+        _check(self._lib.nsg_time_planes(self._h, batch_size, iterations, ctypes.byref(ms), ctypes.byref(nbytes)))
+        return ms.value, nbytes.value
+
     def profile_enable(self, enable=True):
         _check(self._lib.nsg_profile_enable(self._h, 1 if enable else 0))
 
@@ -302,6 +310,13 @@ class Evaluator:
         _check(self._lib.nsg_get_stats(self._h, ctypes.byref(b), ctypes.byref(n)))
         return {"batches": b.value, "positions": n.value,
                 "average_batch": (n.value / b.value) if b.value else 0.0}
+
+    def team_stats(self):
+        """nsg_get_team_stats: is the team trunk in use (1 / 0 / -1 another process holds the device's token),
+        workgroups per board of the most recent team launch, launches re-run on the per-layer kernels."""
+        en, mem, fb = ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64()
+        _check(self._lib.nsg_get_team_stats(self._h, ctypes.byref(en), ctypes.byref(mem), ctypes.byref(fb)))
+        return {"enabled": en.value, "members_last": mem.value, "fallbacks": fb.value}
 
     def last_plan(self):
         """Launch plan of the most recent forward pass (nsg_get_last_plan)."""

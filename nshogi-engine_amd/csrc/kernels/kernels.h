@@ -93,6 +93,7 @@ struct ConvTuning {
     int splitBatch = 1;    // NSG_SPLIT_BATCH=0: never run a batch as a full part + remainder
     int splitBatchMax3 = 9;  // NSG_SPLIT_BATCH_MAX: largest batch, in quarters of the CU count, that starts with a full chip of two-board tiles
     int rowsplit8Max = -1; // NSG_ROWSPLIT8_MAX_BATCH: largest batch whose four-way K split also splits the rows over two workgroups (-1: CUs / 8)
+    int ksplit3 = 1;       // NSG_KSPLIT3=0: 192-channel nets keep the plans they had before the three-way K split
     int slabSplit = 0;     // NSG_SLAB_SPLIT=1: slab-split two-board tiles at mid batches (measured 8-11 % slower than the plans they would replace: opt-in)
     bool fullTilesOnly = false; // kF16m8: 4 fragments per wave at every batch size
 };
@@ -124,9 +125,9 @@ hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
                        const ConvPlan& plan, hipStream_t stream);
 
 // Team trunk (team_trunk.hip): every 3x3 layer of up to sixteen boards in ONE persistent launch, a board per team of
-// 16 / 32 / 96 workgroups that hand activations to each other through agent-scope stores / loads; the payload is
-// its own flag (TeamHandoff).  kF16x3 arithmetic, records and activation layout; 256 trunk channels.  `status`: a
-// host-mapped int the kernel raises when a bounded spin runs out.
+// 16 / 32 / 48 / 96 workgroups (12 / 24 / 36 / 72 for 192 trunk channels) that hand activations to each other through
+// agent-scope stores / loads; the payload is its own flag (TeamHandoff).  kF16x3 arithmetic, records and activation
+// layout; 256 or 192 trunk channels.  `status`: a host-mapped int the kernel raises when a bounded spin runs out.
 typedef unsigned int team_u32x4 __attribute__((ext_vector_type(4)));
 struct TeamLayer {
     const unsigned char* x;   // [boards][81][kdim] kF16x3
@@ -155,12 +156,15 @@ struct TeamHandoff {
     int bitChannels;
 };
 bool teamTrunkSupports(int channels, int stemKdim, int boards);
-int teamMembers(int boards); // workgroups per board of a launch of `boards` boards
+// workgroups per board of a launch of `boards` boards of a `channels`-wide trunk on a device of `computeUnits` CUs
+// (every member must be resident at once); 0: no team size fits.  forceRowGroups > 0: at most that many row groups.
+int teamMembers(int boards, int channels, int computeUnits, int forceRowGroups);
 #ifdef TEAM_STAMPS
 void teamTrunkDumpStamps(); // diagnostic builds: per-phase cycles of one member, printed when an evaluator is destroyed
 #endif
-hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, const TeamHandoff& handoff, int* status,
-                           hipStream_t stream);
+// (shortBy: test hook -- the grid is that many workgroups short, so the last team waits for members that never run)
+hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, int channels, int members,
+                           const TeamHandoff& handoff, int* status, hipStream_t stream, int shortBy = 0);
 
 // Policy 1x1 conv (27 ch, +bias, raw logits -> policy[b][c*81+sq] f32) and
 // value-feature 1x1 conv (VC ch, folded-BN bias, ReLU -> vfeat[b*vfeatStride + sq*VC+c] T)

@@ -633,6 +633,11 @@ _Pragma("unroll") \
         using OS = OwnSeq<SS, PART>; // the slabs of a pair this wave runs, in its own order (SS = 1: all 27)
         static_assert(G::kTaps == 9, "3x3 taps");
         constexpr int kWin = 9, kD = 7; // (five or eight steps of lead: +-0.5 %, profiles/r03/README.md)
+#ifdef NSG_SPREAD_LOADS // A/B build (make ab ABFLAGS=-DNSG_SPREAD_LOADS)
+        constexpr bool kSpread = kMFw > NFRAG; // (fragments 0 .. NFRAG run every tap, edge-packed rows or not)
+#else
+        constexpr bool kSpread = false;
+#endif
         using ST = StepSeq<OS, kMFw, kPerm, kWin>;
         constexpr int kReal = ST::kReal;   // (own slab, fragment) steps that issue MFMAs
         constexpr int kSteps = ST::kSteps; // ... padded to a multiple of the window: a step's slot is the same in every pair
@@ -770,12 +775,18 @@ _Pragma("unroll") \
                     // free once the previous pair's last MX slab is done) and X_j+1 at the top of X_j.
                     const int xj = OS::xOrd(u);
                     const bool reqX = OS::kXCyclic ? xj >= 0 : ((u == 0 && OS::kX > 0) || (xj >= 0 && xj + 1 < OS::kX));
-                    if (f == 0) {
+                    // Record and tile requests of a slab.  kSpread: one fragment's records per step over the slab's first
+                    // NFRAG steps (a vector-memory instruction occupies the wave's issue port longer than the half of an
+                    // MFMA's cycles that are free: four to eight of them behind ONE MFMA hold the next MFMA back; one
+                    // or two per step hide behind that step's own MFMAs) and the tile items in the step behind them.
+                    const int fTile = kSpread ? NFRAG : 0;
+                    if (kSpread ? f < NFRAG : f == 0) {
                         if (!Q::isX(s)) { // f16 record two own main slabs ahead (beyond this pair: the next pair's)
                             const int o2 = OS::mainOrd(u) + 2;
                             const size_t o = (o2 >= OS::kMain ? nextRec : 0) + Q::recOff(OS::mainSlab(o2 % (OS::kMain > 0 ? OS::kMain : 1)));
 #pragma unroll
-                            for (int j = 0; j < NFRAG; ++j) w4[o2 % 3][j] = wc[o * rs + wg4 + j * 64];
+                            for (int j = 0; j < NFRAG; ++j)
+                                if (!kSpread || j == f) w4[o2 % 3][j] = wc[o * rs + wg4 + j * 64];
                         }
                         if (reqX) {
                             const int j2 = OS::kXCyclic ? xj + 1 : ((u == 0 && xj != 0) ? 0 : xj + 1);
@@ -783,11 +794,12 @@ _Pragma("unroll") \
 #pragma unroll
                             for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
-                                for (int h = 0; h < 2; ++h) w8[j2 & 1][j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
+                                for (int h = 0; h < 2; ++h)
+                                    if (!kSpread || j == f) w8[j2 & 1][j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
                         }
                     }
-                    const bool loadA = kStage && f == 0 && u >= kLoadSlabA && u < kLoadSlabA + kLoadSlabs;
-                    const bool loadB = kStage && f == 0 && u >= kLoadSlabB && u < kLoadSlabB + kLoadSlabs;
+                    const bool loadA = kStage && f == fTile && u >= kLoadSlabA && u < kLoadSlabA + kLoadSlabs;
+                    const bool loadB = kStage && f == fTile && u >= kLoadSlabB && u < kLoadSlabB + kLoadSlabs;
                     if (loadA || loadB) {
 #pragma unroll
                         for (int k = u - (loadA ? kLoadSlabA : kLoadSlabB); k < G::kItems; k += kLoadSlabs)
@@ -829,8 +841,8 @@ _Pragma("unroll") \
                         if (Q::isX(OS::slab(ST::pos((q + kD) % kSteps)))) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                         else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
-                    if (f == 0 && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, NFRAG, 0);
-                    if (f == 0 && reqX) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NFRAG, 0);
+                    if ((kSpread ? f < NFRAG : f == 0) && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, kSpread ? 1 : NFRAG, 0);
+                    if ((kSpread ? f < NFRAG : f == 0) && reqX) __builtin_amdgcn_sched_group_barrier(0x020, kSpread ? 2 : 2 * NFRAG, 0);
                     if (loadA || loadB) __builtin_amdgcn_sched_group_barrier(0x020, (G::kItems + kLoadSlabs - 1) / kLoadSlabs, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NFRAG - 1, 0);
                     __builtin_amdgcn_sched_barrier(0);

@@ -27,6 +27,22 @@ hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStrea
         if ((a.kdim / 32) % 8 == 0) return launchOne<kF16m8, kConv, 1, 4, 4, 1, 4>(a, gx, s);
         return launchOne<kF16m8, kConv, 1, 4, 4, 1, 2>(a, gx, s);
     }
+    if (p.ksplit == 3 && p.nb == 1 && p.nwaves == 3) {
+        // 192 channels = three chunk pairs: one 64-channel group per workgroup (three workgroups per board), its three
+        // waves one chunk pair each; the rows over 1, 2, 3 or 6 such workgroups.  A layer that does not have three
+        // pairs (the stem: 128 padded input channels) runs two-wave workgroups, a pair per wave.
+        if ((a.kdim / 32) % 6 == 0) {
+            if (p.msplit == 2) return launchOne<kF16m8, kConv, 1, 4, 3, 2, 3>(a, gx, s);
+            if (p.msplit == 3) return launchOne<kF16m8, kConv, 1, 4, 3, 3, 3>(a, gx, s);
+            if (p.msplit == 6) return launchOne<kF16m8, kConv, 1, 4, 3, 6, 3>(a, gx, s);
+            return launchOne<kF16m8, kConv, 1, 4, 3, 1, 3>(a, gx, s);
+        }
+        if ((a.kdim / 32) % 4 != 0) return hipErrorInvalidValue;
+        if (p.msplit == 2) return launchOne<kF16m8, kConv, 1, 4, 2, 2, 2>(a, gx, s);
+        if (p.msplit == 3) return launchOne<kF16m8, kConv, 1, 4, 2, 3, 2>(a, gx, s);
+        if (p.msplit == 6) return launchOne<kF16m8, kConv, 1, 4, 2, 6, 2>(a, gx, s);
+        return launchOne<kF16m8, kConv, 1, 4, 2, 1, 2>(a, gx, s);
+    }
     if (p.ksplit == 2 && p.nb == 1 && p.nwaves == 4) return launchOne<kF16m8, kConv, 1, 4, 4, 1, 2>(a, gx, s);
     if (p.msplit == 2 && p.nb == 1 && p.nwaves == 4) return launchOne<kF16m8, kConv, 1, 4, 4, 2>(a, gx, s);
 #define NSG_CASE(NB_, NW_) \

@@ -132,18 +132,20 @@ __device__ u64 gTeamStamps[32 * 8];
 #endif
 
 // FR = row fragments per member (1, 2, 3 or all 6: 96, 48, 32 or 16 members per board).
+// nj = weight fragments of a layer = trunk channels / 16 (16 for 256 channels, 12 for 192): a team has nj members per
+// row group.
 template <int FR>
 __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* __restrict__ layers, int nLayers,
-                                                               int boards, TeamHandoff ho, int* status) {
+                                                               int boards, int nj, TeamHandoff ho, int* status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kMembers = 16 * (6 / FR);
+    const int kMembers = nj * (6 / FR);
     constexpr int kSub = FR > 3 ? 3 : FR, kSubs = FR / kSub; // row fragments per fragment-read step, steps per tap
-    // (kMembers is a multiple of 16: block b computes weight fragment b % 16, and under the observed round-robin
-    // placement XCD b % 8 -- an XCD's L2 holds the records of two fragments, for every board)
+    // (kMembers is a multiple of nj: block b computes weight fragment b % nj, and under the observed round-robin
+    // placement XCD b % 8 -- an XCD's L2 holds the records of two (nj = 16) or three (nj = 12) fragments, for every board)
     const int team = (int)(blockIdx.x / kMembers);
     const int rank = (int)(blockIdx.x % kMembers);
     if (team >= boards || rank >= kMembers || team >= kTeamMaxBoards) return;
-    const int j = rank & 15, h = rank >> 4; // weight fragment (16 output channels), row group (half or single fragment)
+    const int j = rank % nj, h = rank / nj; // weight fragment (16 output channels), row group (half or single fragment)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // = this wave's 32-channel chunk of K
     unsigned char* img = smem + wave * kImage;
@@ -199,12 +201,12 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 
     auto loadWeights = [&](const TeamLayer& L, u32x4 (&w)[9][2]) {
         const int nkc = L.kdim / 32;
-        const NSG_GLOBAL u32x4* wp = asGlobal<u32x4>(L.w) + ((size_t)wave * 18 * 16 + j) * 64 + lane; // record q = (chunk*9 + tap)*2 + s, 16 fragments
+        const NSG_GLOBAL u32x4* wp = asGlobal<u32x4>(L.w) + ((size_t)wave * 18 * nj + j) * 64 + lane; // record q = (chunk*9 + tap)*2 + s, nj fragments
         if (wave < nkc) { // (uniform: a branch, not a select that would need the loaded value at once)
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) w[t][s] = wp[(size_t)(t * 2 + s) * 16 * 64];
+                for (int s = 0; s < 2; ++s) w[t][s] = wp[(size_t)(t * 2 + s) * nj * 64];
         }
     };
 
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
         TEAM_STAMP(0)
         // (waves 0..FR-1 also request their residual rows now -- their own stores of two layers ago, long landed)
         const int mOut = (h * FR + (wave < FR ? wave : 0)) * 16 + li;
-        const int rowBase = (team * 81 + (mOut < 81 ? mOut : 0)) * (int)outRow; // (images: 256 channels, the same row size)
+        const int rowBase = (team * 81 + (mOut < 81 ? mOut : 0)) * (int)outRow; // (an image row holds the trunk's channels too: the same row size)
         const int rowImg = rowBase + imgOff;
         const rsrc_t xBuf = bufferOf(xPtr), yBuf = bufferOf(yPtr), oldBuf = bufferOf(oldPtr ? oldPtr : yPtr);
         u32x4 resV = u32x4{0u, 0u, 0u, 0u};
@@ -441,20 +443,28 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 
 } // namespace
 
-// Members per board = 16 weight fragments x row groups, as many as fit the chip's 256 CUs (a member owns a CU: 147 KB
-// of LDS): 96 (one row fragment each) for one or two boards, 48 (two) for three to five, 32 (three) for six to eight,
-// 16 (the whole board) for nine to sixteen.  Measured, evals/s at 2 / 3 / 4 / 5 boards: 96 members 11.2k / - / - / -,
-// 48 members 9.2k / 13.5k / 17.7k / 21.6k, 32 members 7.8k / 11.5k / 15.4k / 18.8k; 6 / 8 boards: 32 members
-// 22.5k / 29.3k, 16 members 16.2k / 21.3k (profiles/r03/g_team_trunk_members.txt).
-// NSG_TEAM_MEMBERS = 16 | 32 | 48 | 96 asks for fewer members than that (or the same).
-int teamMembers(int boards) {
-    static const int force = [] { const char* e = getenv("NSG_TEAM_MEMBERS"); return e ? atoi(e) : 0; }();
-    const int most = boards <= 2 ? 96 : boards <= 5 ? 48 : boards <= 8 ? 32 : 16;
-    return (force == 16 || force == 32 || force == 48 || force == 96) && force < most ? force : most;
+// Members per board = weight fragments (trunk channels / 16: 16 or 12) x row groups, as many as fit the chip's CUs (a
+// member owns a CU: 147 KB of LDS): with 16 fragments on 256 CUs 96 (one row fragment each) for one or two boards,
+// 48 (two) for three to five, 32 (three) for six to eight, 16 (the whole board) for nine to sixteen.  Measured, evals/s
+// at 2 / 3 / 4 / 5 boards: 96 members 11.2k / - / - / -, 48 members 9.2k / 13.5k / 17.7k / 21.6k, 32 members 7.8k /
+// 11.5k / 15.4k / 18.8k; 6 / 8 boards: 32 members 22.5k / 29.3k, 16 members 16.2k / 21.3k
+// (profiles/r03/g_team_trunk_members.txt).  Every member must be resident at once (they wait for each other): a
+// device with fewer CUs (a partition, a CU mask) gets the largest team that fits, or none -- 0 -- and the caller
+// runs the per-layer kernels.  `forceRowGroups` (NSG_TEAM_MEMBERS / 16) asks for fewer row groups than that.
+int teamMembers(int boards, int channels, int computeUnits, int forceRowGroups) {
+    const int nj = channels / 16;
+    for (int rg : {6, 3, 2, 1}) {
+        if (forceRowGroups > 0 && rg > forceRowGroups) continue;
+        if ((long)boards * nj * rg <= computeUnits) return nj * rg;
+    }
+    return 0;
 }
 
+// 256 or 192 trunk channels: a member's eight waves take one 32-channel chunk of K each (a wave's share of a layer's
+// records is 72 registers), so at most eight chunks; rows of an image are 1024 bytes.
 bool teamTrunkSupports(int channels, int stemKdim, int boards) {
-    return channels == 256 && stemKdim % 32 == 0 && stemKdim <= 256 && boards >= 1 && boards <= kTeamMaxBoards;
+    return (channels == 256 || channels == 192) && stemKdim % 32 == 0 && stemKdim <= 256 && boards >= 1 &&
+           boards <= kTeamMaxBoards;
 }
 
 #ifdef TEAM_STAMPS
@@ -475,11 +485,15 @@ void teamTrunkDumpStamps() {
 }
 #endif
 
-hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, const TeamHandoff& handoff, int* status,
-                           hipStream_t stream) {
+hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, int channels, int members,
+                           const TeamHandoff& handoff, int* status, hipStream_t stream, int shortBy) {
+    const int nj = channels / 16;
     if (nLayers < 3 || boards < 1 || boards > kTeamMaxBoards || !handoff.set || !handoff.other ||
+        !teamTrunkSupports(channels, 32, boards) || members % nj != 0 ||
         handoff.imageStride < (size_t)boards * 81 * 1024 || handoff.imageStride < (size_t)handoff.cleanBoards * 81 * 1024)
         return hipErrorInvalidValue;
+    const int rowGroups = members / nj;
+    if (rowGroups != 1 && rowGroups != 2 && rowGroups != 3 && rowGroups != 6) return hipErrorInvalidValue;
     // (the attribute belongs to a function ON a device: one process may drive several -- selfplay --num-gpus)
     static std::atomic<unsigned long long> attrDevMask{0};
     int dev = 0;
@@ -493,18 +507,16 @@ hipError_t launchTeamTrunk(const TeamLayer* devLayers, int nLayers, int boards, 
         }
         attrDevMask.fetch_or(1ull << (dev & 63));
     }
-    if (teamMembers(boards) == 96)
-        hipLaunchKernelGGL(teamTrunkKernel<1>, dim3(boards * 96), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
-                           handoff, status);
-    else if (teamMembers(boards) == 48)
-        hipLaunchKernelGGL(teamTrunkKernel<2>, dim3(boards * 48), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
-                           handoff, status);
-    else if (teamMembers(boards) == 16)
-        hipLaunchKernelGGL(teamTrunkKernel<6>, dim3(boards * 16), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
-                           handoff, status);
+    if (shortBy < 0 || shortBy >= boards * members) return hipErrorInvalidValue;
+    const dim3 grid(boards * members - shortBy), block(kThreads);
+    if (rowGroups == 6)
+        hipLaunchKernelGGL(teamTrunkKernel<1>, grid, block, kLds, stream, devLayers, nLayers, boards, nj, handoff, status);
+    else if (rowGroups == 3)
+        hipLaunchKernelGGL(teamTrunkKernel<2>, grid, block, kLds, stream, devLayers, nLayers, boards, nj, handoff, status);
+    else if (rowGroups == 1)
+        hipLaunchKernelGGL(teamTrunkKernel<6>, grid, block, kLds, stream, devLayers, nLayers, boards, nj, handoff, status);
     else
-        hipLaunchKernelGGL(teamTrunkKernel<3>, dim3(boards * 32), dim3(kThreads), kLds, stream, devLayers, nLayers, boards,
-                           handoff, status);
+        hipLaunchKernelGGL(teamTrunkKernel<3>, grid, block, kLds, stream, devLayers, nLayers, boards, nj, handoff, status);
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@ ConvTuning readConvTuning() {
     if (const char* e = getenv("NSG_SPLIT_BATCH")) t.splitBatch = atoi(e);
     if (const char* e = getenv("NSG_SPLIT_BATCH_MAX")) t.splitBatchMax3 = atoi(e);
     if (const char* e = getenv("NSG_SLAB_SPLIT")) t.slabSplit = atoi(e);
+    if (const char* e = getenv("NSG_KSPLIT3")) t.ksplit3 = atoi(e);
     return t;
 }
 

@@ -13,7 +13,11 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <strings.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -321,6 +325,22 @@ struct nsg_evaluator {
     int teamDirty[2] = {0, 0}; // boards of each set that do not hold the sentinel
     int teamLayerCount = 0;
     int teamEnabled = 1;
+    int teamForceRowGroups = 0; // NSG_TEAM_MEMBERS / 16, read when the evaluator is created (0: as many as fit)
+    int teamMaxBatch = nsg::kTeamMaxBoards; // NSG_TEAM_MAX_BATCH, likewise
+    int teamLastMembers = 0; // workgroups per board of the most recent team launch
+    uint64_t teamFallbacks = 0; // team launches that gave up and were re-run on the per-layer kernels (nsg_get_team_stats)
+    int teamLockedOut = 0;      // another PROCESS holds this device's team token (teamDeviceLock): per-layer kernels only
+    bool teamLockHeld = false;  // this evaluator holds a reference on the process's lock of the device
+    int teamFaultLaunches = 0;  // NSG_TEAM_FAULT_LAUNCHES (test hook): this many team launches are made ONE WORKGROUP SHORT,
+                                // so that the team waits in vain, gives up and the recovery path runs
+    // What the most recent compute call queued behind its forward: should the team launch of that forward give up
+    // (teamRecover), the same batch is re-run on the per-layer kernels and these copies are issued again.
+    struct Pending {
+        int kind = 0; // 0 nothing, 1 nsg_compute_nonblocking, 2 nsg_compute_gather_nonblocking, 3 nsg_forward_resident
+        size_t n = 0, total = 0;
+        int softmax = 0;
+        float* pol = nullptr; float* win = nullptr; float* draw = nullptr; float* vals = nullptr;
+    } pending;
     hipEvent_t teamDone = nullptr; // behind this evaluator's most recent team launch (the token's next holder waits for it)
     int* teamStatusHost = nullptr; // host-mapped: raised by the kernel when a bounded spin runs out
     int* teamStatusDev = nullptr;
@@ -464,8 +484,70 @@ void releaseTeamToken(nsg_evaluator* ev) {
     if (gTeamOwner[ev->gpu & 63] == ev) gTeamOwner[ev->gpu & 63] = nullptr;
 }
 
+// ... and one PROCESS per device: two processes' team launches would starve each other the same way, and no stream
+// event reaches across processes.  The first evaluator of a process that builds a team layer list for a device takes
+// an advisory lock (flock, released when the process ends) on a file named after the device's PCI bus id; a process
+// that finds the lock taken keeps to the per-layer kernels on that device.  (A file system the other process does
+// not share -- another container -- is not covered: there the bounded spins and teamRecover are what is left.)
+// The lock is counted: the last evaluator of the process that used it gives it back (nsg_destroy).
+// NSG_TEAM_LOCK_DIR names the directory of the lock files (default /dev/shm, then /tmp) -- for processes that share a
+// device but not those directories.  Returns false only when ANOTHER process holds the lock.
+struct TeamDeviceLocks {
+    std::mutex m;
+    int fd[64];
+    int refs[64];
+    TeamDeviceLocks() { for (int i = 0; i < 64; ++i) { fd[i] = -1; refs[i] = 0; } }
+};
+TeamDeviceLocks& teamLocks() {
+    static TeamDeviceLocks t;
+    return t;
+}
+bool teamDeviceLock(int gpu) {
+    TeamDeviceLocks& T = teamLocks();
+    std::lock_guard<std::mutex> lock(T.m);
+    const int g = gpu & 63;
+    if (T.refs[g] > 0) { ++T.refs[g]; return true; } // this process holds it (or found nothing to lock: fd -1)
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), gpu) != hipSuccess || !bus[0]) snprintf(bus, sizeof(bus), "gpu%d", gpu);
+    for (char* c = bus; *c; ++c)
+        if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+    const char* envDir = getenv("NSG_TEAM_LOCK_DIR");
+    const char* dirs[2] = {envDir && *envDir ? envDir : "/dev/shm", envDir && *envDir ? nullptr : "/tmp"};
+    for (const char* dir : dirs) {
+        if (!dir) continue;
+        char path[512];
+        snprintf(path, sizeof(path), "%s/nsg_team_token_%s.lock", dir, bus);
+        const mode_t old = umask(0);
+        const int f = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        umask(old);
+        if (f < 0) continue;
+        if (flock(f, LOCK_EX | LOCK_NB) == 0) { T.fd[g] = f; T.refs[g] = 1; return true; }
+        const bool taken = errno == EWOULDBLOCK;
+        close(f);
+        if (taken) return false;
+    }
+    T.fd[g] = -1; // no lock file could be opened: nothing to coordinate through (see above)
+    T.refs[g] = 1;
+    return true;
+}
+void teamDeviceUnlock(int gpu) {
+    TeamDeviceLocks& T = teamLocks();
+    std::lock_guard<std::mutex> lock(T.m);
+    const int g = gpu & 63;
+    if (T.refs[g] > 0 && --T.refs[g] == 0 && T.fd[g] >= 0) {
+        close(T.fd[g]); // (closing the descriptor gives the flock back)
+        T.fd[g] = -1;
+    }
+}
+
+// Workgroups per board of a team launch of B boards on this evaluator's device; 0: the batch does not run as a team.
+int teamMembersFor(const nsg_evaluator* ev, int B) {
+    if (ev->teamLayerCount <= 0 || !ev->teamEnabled || B > ev->teamMaxBatch) return 0;
+    return nsg::teamMembers(B, ev->F, ev->prop.multiProcessorCount, ev->teamForceRowGroups);
+}
+
 // The whole forward of a batch of at most kTeamMaxBoards boards with the team trunk.
-int enqueueTeam(nsg_evaluator* ev, int B, hipStream_t s, hipEvent_t trunkBegin, hipEvent_t trunkEnd) {
+int enqueueTeam(nsg_evaluator* ev, int B, int members, hipStream_t s, hipEvent_t trunkBegin, hipEvent_t trunkEnd) {
     const int prec = nsg::kF16x3;
     ev->lastTrunkPrec = prec;
     {   // (the feature bitboards are decoded by the first layer of the team launch itself)
@@ -479,8 +561,11 @@ int enqueueTeam(nsg_evaluator* ev, int B, hipStream_t s, hipEvent_t trunkBegin, 
         ho.cleanBoards = ev->teamDirty[1 - ev->teamSet];
         ho.bits = ev->input.p;
         ho.bitChannels = ev->numChannels;
-        NSG_HIP(nsg::launchTeamTrunk((const nsg::TeamLayer*)ev->teamLayers.p, ev->teamLayerCount, B, ho,
-                                     ev->teamStatusDev, s));
+        const int shortBy = ev->teamFaultLaunches > 0 ? 1 : 0;
+        if (shortBy) --ev->teamFaultLaunches;
+        NSG_HIP(nsg::launchTeamTrunk((const nsg::TeamLayer*)ev->teamLayers.p, ev->teamLayerCount, B, ev->F, members, ho,
+                                     ev->teamStatusDev, s, shortBy));
+        ev->teamLastMembers = members;
         NSG_HIP(hipEventRecord(ev->teamDone, s)); // (under the token's mutex: enqueueForward)
         ev->teamDirty[1 - ev->teamSet] = 0;
         ev->teamDirty[ev->teamSet] = B;
@@ -612,6 +697,23 @@ nsg::ConvPlan planForBatch(nsg_evaluator* ev, int B) {
         }
     }
 
+    // 192 channels (BASELINE configs[1]: 10x192 at batch 64) are three chunk pairs: up to CUs/3 boards run one
+    // 64-channel group per workgroup whose three waves take one pair each, all of the board's chunk tiles resident
+    // (the four-way K split of the 256-channel nets, three ways), the rows over as many workgroups as fit one round.
+    if (mx && ev->F == 192 && ev->cpad == 128 && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 && ev->tuning.nwaves == 0 &&
+        ev->tuning.msplit != 2 && ev->tuning.ksplit3 != 0) {
+        const long cus = ev->prop.multiProcessorCount;
+        if ((long)B * 3 <= cus) {
+            plan = nsg::ConvPlan{};
+            plan.nb = 1; plan.nfrag = 4; plan.nwaves = 3; plan.msplit = 1; plan.ksplit = 3;
+            if (ev->tuning.msplit != 1) {
+                if ((long)B * 18 <= cus) plan.msplit = 6;
+                else if ((long)B * 9 <= cus) plan.msplit = 3;
+                else if ((long)B * 6 <= cus) plan.msplit = 2;
+            }
+        }
+    }
+
     // Mid batches, MX arithmetic: two-board tiles of ONE 64-channel group (or two) per workgroup whose waves split
     // every chunk pair's slabs between them (mfma_tile.h, OwnSeq) -- where one workgroup per (two boards, group)
     // fills more than half the CUs in one round and the four-workgroups-per-board K split does not apply.  Against
@@ -658,21 +760,28 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // (kernels/team_trunk.hip), when no tuning override asks for a particular per-layer plan and no other evaluator
     // has a team launch in flight on this device.
     ev->teamLast = false;
-    static const int teamMax = [] { const char* e = getenv("NSG_TEAM_MAX_BATCH"); const int v = e ? atoi(e) : nsg::kTeamMaxBoards;
-                                    return v < 0 ? 0 : (v > nsg::kTeamMaxBoards ? nsg::kTeamMaxBoards : v); }();
-    if (ev->teamLayerCount > 0 && ev->teamEnabled && B <= teamMax && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 &&
-        ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && !ev->useTrunkKernel) {
+    // (a give-up word still raised here belongs to a forward nobody waited for: its batch is gone, the team path is not
+    // taken again)
+    if (ev->teamStatusHost && *ev->teamStatusHost != 0) {
+        *ev->teamStatusHost = 0;
+        ev->teamEnabled = 0;
+        ++ev->teamFallbacks;
+        releaseTeamToken(ev);
+    }
+    const int members = (ev->tuning.nb == 0 && ev->tuning.nfrag == 0 && ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 &&
+                         !ev->useTrunkKernel) ? teamMembersFor(ev, B) : 0;
+    if (members > 0) {
         int rc;
         {
             TeamTokenGuard token(ev);
             if (!token.held) return fail(NSG_E_HIP, "team trunk: hipStreamWaitEvent on the device's other team launch failed");
-            rc = enqueueTeam(ev, B, s, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
+            rc = enqueueTeam(ev, B, members, s, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
         }
         if (rc) return rc;
         ev->teamLast = true;
         plan = nsg::ConvPlan{};
         plan.nb = 1; plan.nfrag = 1; plan.nwaves = 8; plan.ksplit = 8; // 16 weight fragments x 2 or 6 row groups per board, K over 8 waves
-        plan.msplit = nsg::teamMembers(B) / 16;
+        plan.msplit = members / (ev->F / 16); // row groups
         ev->lastPlan = plan;
         ev->lastChains = 1;
         if (prof) {
@@ -906,6 +1015,14 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
         ev->teamLayerCount = nl;
         const char* env = getenv("NSG_TEAM_TRUNK");
         ev->teamEnabled = (env && env[0] == '0') ? 0 : 1;
+        if (ev->teamEnabled && !ev->teamLockHeld) {
+            if (teamDeviceLock(ev->gpu)) {
+                ev->teamLockHeld = true;
+            } else { // another process runs team launches on this device
+                ev->teamEnabled = 0;
+                ev->teamLockedOut = 1;
+            }
+        }
     }
     NSG_HIP(hipDeviceSynchronize());
     ev->calibKey = -1; // a new network: re-measure the layer time for the chain stagger
@@ -922,6 +1039,51 @@ int checkCompute(nsg_evaluator* ev, size_t n) {
     // the calling thread may never have called resetGPU for this evaluator (a pipeline's launch
     // thread, a self-play worker's second executor): every launch below must go to ev's device
     return bind(ev);
+}
+
+// What a compute call queues behind its forward: the legal-move gather and the D2H copies (trt.cc:265-271).
+int enqueueOutputs(nsg_evaluator* ev) {
+    const nsg_evaluator::Pending& P = ev->pending;
+    if (P.kind == 1) {
+        NSG_HIP(hipMemcpyAsync(P.pol, ev->policy.p, P.n * NSG_MOVE_INDEX_MAX * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
+    } else if (P.kind == 2) {
+        if (P.total) {
+            NSG_HIP(nsg::launchGatherLogits((const float*)ev->policy.p, (const uint16_t*)ev->moveIdx.p,
+                                            (const uint32_t*)ev->moveOff.p, (float*)ev->gathered.p, (int)P.n, P.softmax, ev->stream));
+            NSG_HIP(hipMemcpyAsync(P.vals, ev->gathered.p, P.total * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
+        }
+    } else {
+        return NSG_OK;
+    }
+    NSG_HIP(hipMemcpyAsync(P.win, ev->value.p, P.n * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
+    NSG_HIP(hipMemcpyAsync(P.draw, ev->draw.p, P.n * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
+    return NSG_OK;
+}
+
+// Called behind every synchronisation of ev->stream that may follow a forward.  A team launch whose members waited
+// for each other in vain (a device partition smaller than the grid, another process's persistent kernel on the CUs)
+// has raised the host-mapped give-up word and unwound; what it left in the output buffers is undefined.  The batch
+// is still in ev->input (and the gather's indices in ev->moveIdx): run it again on the per-layer kernels, issue the
+// call's copies again, wait.  The team path stays off for this evaluator from here on; nsg_get_team_stats counts.
+int teamRecover(nsg_evaluator* ev) {
+    if (!ev->teamStatusHost || *ev->teamStatusHost == 0) return NSG_OK;
+    *ev->teamStatusHost = 0;
+    ev->teamEnabled = 0;
+    ++ev->teamFallbacks;
+    releaseTeamToken(ev);
+    if (ev->pending.kind == 0 || ev->pending.n == 0 || !ev->teamLast) return NSG_OK;
+    --ev->statBatches; // (the same batch, not a new one)
+    ev->statPositions -= ev->pending.n;
+    int rc = enqueueForward(ev, ev->pending.n);
+    if (rc) return rc;
+    if ((rc = enqueueOutputs(ev))) return rc;
+    NSG_HIP(hipStreamSynchronize(ev->stream));
+    return NSG_OK;
+}
+
+int syncAndRecover(nsg_evaluator* ev) {
+    NSG_HIP(hipStreamSynchronize(ev->stream));
+    return teamRecover(ev);
 }
 
 } // namespace
@@ -946,15 +1108,19 @@ static int checkTuningEnv() {
         {"NSG_SPLIT_BATCH_MAX", 0, 64, "largest batch (quarters of the CU count) that starts with a full chip of two-board tiles"}, {"NSG_ROCTX", 0, 1, "profiler markers"},
         {"NSG_SHARED_FORCE_COPY", 0, 1, "nsg_load_shared copies even on one device"},
         {"NSG_SLAB_SPLIT", 0, 1, "slab-split two-board tiles at mid batches"},
+        {"NSG_KSPLIT3", 0, 1, "three-way K split of 192-channel nets at small and mid batches"},
         {"NSG_TEAM_TRUNK", 0, 1, "team trunk for the smallest batches"},
         {"NSG_TEAM_MAX_BATCH", 0, 16, "largest batch that runs the team trunk"},
-        {"NSG_TEAM_MEMBERS", 16, 96, "workgroups per board of the team trunk (16, 32 or 96)"}};
+        {"NSG_TEAM_FAULT_LAUNCHES", 0, 1000000, "test hook: team launches made one workgroup short"},
+        {"NSG_TEAM_MEMBERS", 16, 96, "most workgroups per board of the team trunk on a 256-channel net: 16, 32, 48 or 96 "
+                                     "(= 1, 2, 3 or 6 row groups; a 192-channel net runs 12 per row group)"}};
     for (const Var& v : vars) {
         const char* e = getenv(v.name);
         if (!e) continue;
         char* end = nullptr;
         const long x = strtol(e, &end, 10);
-        const bool bad = end == e || *end != 0 || x < v.lo || x > v.hi || (!strcmp(v.name, "NSG_CONV_NFRAG") && x == 3);
+        const bool bad = end == e || *end != 0 || x < v.lo || x > v.hi || (!strcmp(v.name, "NSG_CONV_NFRAG") && x == 3) ||
+                         (!strcmp(v.name, "NSG_TEAM_MEMBERS") && x != 16 && x != 32 && x != 48 && x != 96);
         if (bad) return fail(NSG_E_INVALID, "%s=%s: expected an integer in [%ld, %ld] (%s)", v.name, e, v.lo, v.hi, v.what);
     }
     return NSG_OK;
@@ -1017,6 +1183,9 @@ int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator**
     for (auto& ce : ev->calibEv) NSG_HIP(hipEventCreate(&ce));
     if (const char* e2 = getenv("NSG_CHAIN_DELAY_US")) ev->chainDelayUs = std::max(-1, atoi(e2));
     if (const char* e2 = getenv("NSG_CHAIN_MIN_BATCH")) ev->chainMinBatch = std::max(2, atoi(e2));
+    if (const char* e2 = getenv("NSG_TEAM_MEMBERS")) ev->teamForceRowGroups = atoi(e2) / 16; // (validated above)
+    if (const char* e2 = getenv("NSG_TEAM_FAULT_LAUNCHES")) ev->teamFaultLaunches = std::max(0, atoi(e2));
+    if (const char* e2 = getenv("NSG_TEAM_MAX_BATCH")) ev->teamMaxBatch = std::min(std::max(0, atoi(e2)), (int)nsg::kTeamMaxBoards);
     *out = ev.release();
     return NSG_OK;
 }
@@ -1027,7 +1196,9 @@ int nsg_destroy(nsg_evaluator* ev) {
     if (ev->stream) {
         (void)hipStreamSynchronize(ev->stream);
     }
+    if (ev->teamStatusHost) *ev->teamStatusHost = 0;
     releaseTeamToken(ev);
+    if (ev->teamLockHeld) teamDeviceUnlock(ev->gpu);
 #ifdef TEAM_STAMPS
     if (ev->teamLayerCount) nsg::teamTrunkDumpStamps();
 #endif
@@ -1290,16 +1461,10 @@ int nsg_compute_nonblocking(nsg_evaluator* ev, const void* features, size_t batc
                                batch_size * ev->numChannels * NSG_BITBOARD_BYTES,
                                hipMemcpyHostToDevice, ev->stream));
     }
+    ev->pending = nsg_evaluator::Pending{1, batch_size, 0, 0, dst_policy, dst_win_rate, dst_draw_rate, nullptr};
     if ((rc = enqueueForward(ev, batch_size))) return rc;
     Range d2h("nsg.d2h");
-    // trt.cc:265-271
-    NSG_HIP(hipMemcpyAsync(dst_policy, ev->policy.p, batch_size * NSG_MOVE_INDEX_MAX * sizeof(float),
-                           hipMemcpyDeviceToHost, ev->stream));
-    NSG_HIP(hipMemcpyAsync(dst_win_rate, ev->value.p, batch_size * sizeof(float),
-                           hipMemcpyDeviceToHost, ev->stream));
-    NSG_HIP(hipMemcpyAsync(dst_draw_rate, ev->draw.p, batch_size * sizeof(float),
-                           hipMemcpyDeviceToHost, ev->stream));
-    return NSG_OK;
+    return enqueueOutputs(ev); // trt.cc:265-271
 }
 
 int nsg_compute_gather_nonblocking(nsg_evaluator* ev, const void* features, size_t batch_size,
@@ -1331,16 +1496,9 @@ int nsg_compute_gather_nonblocking(nsg_evaluator* ev, const void* features, size
     if (total)
         NSG_HIP(hipMemcpyAsync(ev->moveIdx.p, move_indices, total * sizeof(uint16_t), hipMemcpyHostToDevice,
                                ev->stream));
+    ev->pending = nsg_evaluator::Pending{2, batch_size, total, softmax ? 1 : 0, nullptr, dst_win_rate, dst_draw_rate, dst_values};
     if ((rc = enqueueForward(ev, batch_size))) return rc;
-    if (total) {
-        NSG_HIP(nsg::launchGatherLogits((const float*)ev->policy.p, (const uint16_t*)ev->moveIdx.p,
-                                        (const uint32_t*)ev->moveOff.p, (float*)ev->gathered.p, (int)batch_size,
-                                        softmax ? 1 : 0, ev->stream));
-        NSG_HIP(hipMemcpyAsync(dst_values, ev->gathered.p, total * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
-    }
-    NSG_HIP(hipMemcpyAsync(dst_win_rate, ev->value.p, batch_size * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
-    NSG_HIP(hipMemcpyAsync(dst_draw_rate, ev->draw.p, batch_size * sizeof(float), hipMemcpyDeviceToHost, ev->stream));
-    return NSG_OK;
+    return enqueueOutputs(ev);
 }
 
 int nsg_compute_gather_blocking(nsg_evaluator* ev, const void* features, size_t batch_size,
@@ -1355,15 +1513,11 @@ int nsg_compute_gather_blocking(nsg_evaluator* ev, const void* features, size_t 
 
 int nsg_await(nsg_evaluator* ev) {
     if (!ev) return fail(NSG_E_INVALID, "null evaluator");
-    NSG_HIP(hipStreamSynchronize(ev->stream)); // trt.cc:281-283
-    if (ev->teamStatusHost && *ev->teamStatusHost != 0) {
-        *ev->teamStatusHost = 0;
-        ev->teamEnabled = 0; // the per-layer kernels from here on
-        releaseTeamToken(ev);
-        return fail(NSG_E_HIP, "team trunk launch timed out waiting for its members (another persistent launch on this "
-                               "device?); outputs of this batch are undefined, later batches use the per-layer kernels");
-    }
-    return NSG_OK;
+    int rc = bind(ev);
+    if (rc) return rc;
+    // trt.cc:281-283; a team launch that gave up is re-run on the per-layer kernels before this returns (teamRecover):
+    // the caller sees a slow batch, not a lost one
+    return syncAndRecover(ev);
 }
 
 int nsg_compute_blocking(nsg_evaluator* ev, const void* features, size_t batch_size,
@@ -1416,6 +1570,8 @@ int nsg_upload_features(nsg_evaluator* ev, const void* features, size_t batch_si
         return fail(NSG_E_INVALID, "bad upload_features argument");
     int rc = bind(ev);
     if (rc) return rc;
+    if ((rc = syncAndRecover(ev))) return rc; // (before the batch a forward in flight still reads is overwritten)
+    ev->pending = nsg_evaluator::Pending{};
     NSG_HIP(hipMemcpyAsync(ev->input.p, features, batch_size * ev->numChannels * NSG_BITBOARD_BYTES,
                            hipMemcpyHostToDevice, ev->stream));
     NSG_HIP(hipStreamSynchronize(ev->stream));
@@ -1425,6 +1581,7 @@ int nsg_upload_features(nsg_evaluator* ev, const void* features, size_t batch_si
 int nsg_forward_resident(nsg_evaluator* ev, size_t batch_size) {
     int rc = checkCompute(ev, batch_size);
     if (rc) return rc;
+    ev->pending = nsg_evaluator::Pending{3, batch_size, 0, 0, nullptr, nullptr, nullptr, nullptr};
     return enqueueForward(ev, batch_size);
 }
 
@@ -1432,6 +1589,7 @@ int nsg_download_outputs(nsg_evaluator* ev, size_t batch_size, float* dst_policy
                          float* dst_win_rate, float* dst_draw_rate) {
     int rc = checkCompute(ev, batch_size);
     if (rc) return rc;
+    if ((rc = syncAndRecover(ev))) return rc;
     NSG_HIP(hipMemcpyAsync(dst_policy, ev->policy.p, batch_size * NSG_MOVE_INDEX_MAX * sizeof(float),
                            hipMemcpyDeviceToHost, ev->stream));
     NSG_HIP(hipMemcpyAsync(dst_win_rate, ev->value.p, batch_size * sizeof(float),
@@ -1446,6 +1604,7 @@ int nsg_download_trunk(nsg_evaluator* ev, size_t batch_size, float* dst) {
     int rc = checkCompute(ev, batch_size);
     if (rc) return rc;
     if (!ev->trunkOut) return fail(NSG_E_INVALID, "no forward has run yet");
+    if ((rc = syncAndRecover(ev))) return rc;
     const size_t bytes = batch_size * ev->F * 81 * sizeof(float);
     if (ev->scratch.bytes < bytes && (rc = ev->scratch.alloc(bytes, false))) return rc;
     NSG_HIP(nsg::launchActToNCHW(ev->trunkOut, (float*)ev->scratch.p, (int)batch_size, ev->F,
@@ -1459,6 +1618,7 @@ int nsg_download_planes_raw(nsg_evaluator* ev, size_t batch_size, void* dst, siz
     int rc = checkCompute(ev, batch_size);
     if (rc) return rc;
     if (!ev->trunkOut) return fail(NSG_E_INVALID, "no forward has run yet");
+    if ((rc = syncAndRecover(ev))) return rc;
     if (ev->teamLast)
         return fail(NSG_E_INVALID, "the last forward ran the team trunk, which decodes the bitboards inside its first layer: "
                                    "there is no plane buffer for it (NSG_TEAM_TRUNK=0 keeps the per-layer kernels)");
@@ -1470,6 +1630,33 @@ int nsg_download_planes_raw(nsg_evaluator* ev, size_t batch_size, void* dst, siz
     NSG_HIP(hipMemcpyAsync(dst, ev->planes.p, bytes, hipMemcpyDeviceToHost, ev->stream));
     NSG_HIP(hipStreamSynchronize(ev->stream));
     *row_bytes = rb;
+    return NSG_OK;
+}
+
+int nsg_time_planes(nsg_evaluator* ev, size_t batch_size, int iterations, float* avg_ms, double* bytes_per_launch) {
+    int rc = checkCompute(ev, batch_size);
+    if (rc) return rc;
+    if (iterations < 1 || !avg_ms) return fail(NSG_E_INVALID, "bad time_planes argument");
+    if ((rc = syncAndRecover(ev))) return rc;
+    const int prec = ev->prec;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    NSG_HIP(hipEventCreate(&e0));
+    NSG_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, (int)batch_size, ev->numChannels, ev->cpad, prec, ev->stream));
+    NSG_HIP(hipEventRecord(e0, ev->stream));
+    for (int i = 0; i < iterations; ++i)
+        NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, (int)batch_size, ev->numChannels, ev->cpad, prec, ev->stream));
+    NSG_HIP(hipEventRecord(e1, ev->stream));
+    NSG_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    NSG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)iterations;
+    // algorithmic bytes: the bitboards read + the trunk-input rows written ([81][cpad] elements per position)
+    if (bytes_per_launch)
+        *bytes_per_launch = (double)batch_size * ((double)ev->numChannels * NSG_BITBOARD_BYTES + 81.0 * ev->cpad * nsg::elemSize(prec));
     return NSG_OK;
 }
 
@@ -1504,6 +1691,14 @@ int nsg_get_stats(nsg_evaluator* ev, uint64_t* batches, uint64_t* positions) {
     if (!ev) return fail(NSG_E_INVALID, "null evaluator");
     if (batches) *batches = ev->statBatches;
     if (positions) *positions = ev->statPositions;
+    return NSG_OK;
+}
+
+int nsg_get_team_stats(nsg_evaluator* ev, int* enabled, int* members_last, uint64_t* fallbacks) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    if (enabled) *enabled = (ev->teamLayerCount > 0 && ev->teamEnabled) ? 1 : (ev->teamLockedOut ? -1 : 0);
+    if (members_last) *members_last = ev->teamLastMembers;
+    if (fallbacks) *fallbacks = ev->teamFallbacks;
     return NSG_OK;
 }
 
@@ -1577,44 +1772,7 @@ int nsg_debug_stamps_read(nsg_evaluator* ev, unsigned long long* dst) {
 }
 #endif
 
-// ---------------------------------------------------------------------------
-// CPU stand-in executors (src/infer/zero.cc, nothing.cc, random.cc).
-// ---------------------------------------------------------------------------
-struct nsg_cpu_executor {
-    int kind;
-    std::mt19937_64 rng; // random.h:41
-};
-
-int nsg_cpu_executor_create(int kind, uint64_t seed, nsg_cpu_executor** out) {
-    if (!out || kind < 0 || kind > 2) return fail(NSG_E_INVALID, "bad cpu executor kind");
-    *out = new nsg_cpu_executor{kind, std::mt19937_64(seed)}; // random.cc:21-23
-    return NSG_OK;
-}
-
-int nsg_cpu_executor_destroy(nsg_cpu_executor* ex) {
-    delete ex;
-    return NSG_OK;
-}
-
-int nsg_cpu_executor_compute(nsg_cpu_executor* ex, const void*, size_t batch_size,
-                             float* dst_policy, float* dst_win_rate, float* dst_draw_rate) {
-    if (!ex) return fail(NSG_E_INVALID, "null executor");
-    if (ex->kind == 0) { // zero.cc:25-31
-        memset(dst_policy, 0, batch_size * NSG_MOVE_INDEX_MAX * sizeof(float));
-        memset(dst_win_rate, 0, batch_size * sizeof(float));
-        memset(dst_draw_rate, 0, batch_size * sizeof(float));
-    } else if (ex->kind == 2) { // random.cc:28-42
-        // one distribution object shared by every executor, as the
-        // function-static of random.cc:32 is
-        static std::uniform_real_distribution<float> distribution(0, 1);
-        for (size_t i = 0; i < batch_size; ++i) {
-            for (size_t j = 0; j < NSG_MOVE_INDEX_MAX; ++j)
-                dst_policy[i * NSG_MOVE_INDEX_MAX + j] = distribution(ex->rng);
-            dst_win_rate[i] = distribution(ex->rng);
-            dst_draw_rate[i] = distribution(ex->rng);
-        }
-    } // kind 1 = Nothing: nothing.cc:22-24
-    return NSG_OK;
-}
+// (the CPU stand-in executors nsg_cpu_executor_* live in cpu_executor.cc: host-only code, built with the
+// reference's release flags)
 
 } // extern "C"

@@ -31,12 +31,16 @@ def err(a, b):
 
 
 def test_config1_10x192_batch64_default_precision(nsg, oracle):
-    """configs[1] in bench.py's default arithmetic (f16m6).  At 192 channels and 64 boards an MX
-    evaluator runs its f16x3 small tiles (f32-equivalent): every 8th board against the oracle."""
+    """configs[1] in bench.py's default arithmetic (f16m6).  192 channels are three chunk pairs: 64 boards run
+    three workgroups per board, one 64-channel group each, whose three waves split K by pair -- in the MX
+    arithmetic (round 4; before, the f16x3 small tiles): every 8th board against the oracle."""
     ev, blob = make(nsg, 10, 192, 64, "f16m6", seed=1)
     bb = nsg.synth.random_batch(64, 86, seed=2)
     p, v, d = ev.compute_blocking(bb)
-    assert ev.last_plan()["trunk_precision"] in ("f16x3", "f16m6")
+    cus = ev.info()["compute_units"]
+    assert ev.last_plan()["trunk_precision"] == ("f16m6" if 64 * 3 <= cus else "f16x3"), ev.last_plan()
+    if 64 * 3 <= cus:
+        assert ev.last_plan()["k_split"] == 3 and ev.last_plan()["waves_per_group"] == 3
     idx = list(range(0, 64, 8)) + [63]
     assert err((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx])) < TOL
     perm = np.random.default_rng(0).permutation(64)

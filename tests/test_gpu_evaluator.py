@@ -2,6 +2,9 @@
 vs the committed golden fixture, and size-independent properties at
 BASELINE.json's full sizes.  Tolerance for the network outputs is the
 north_star's 1e-3 (fp32 path); reduced-precision paths state their own."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -667,7 +670,7 @@ def test_host_stats_and_profiler_markers(nsg, tmp_path):
 def test_tuning_variables_are_validated(nsg, monkeypatch):
     """A tuning variable outside its domain is refused when the evaluator is created."""
     for name, bad in (("NSG_CONV_NB", "3"), ("NSG_CONV_NFRAG", "3"), ("NSG_CHAINS", "two"), ("NSG_TRUNK_KERNEL", "yes"),
-                      ("NSG_CONV_MSPLIT", "0")):
+                      ("NSG_CONV_MSPLIT", "0"), ("NSG_TEAM_MEMBERS", "64"), ("NSG_TEAM_MAX_BATCH", "17")):
         monkeypatch.setenv(name, bad)
         with pytest.raises(nsg.NsgError, match=name):
             nsg.Evaluator(0, 4, 86)
@@ -958,3 +961,173 @@ def test_planes_download_after_a_team_forward_fails_loudly(nsg):
     assert ev.last_plan()["k_split"] == 8  # the team trunk
     with pytest.raises(nsg.NsgError, match="team trunk"):
         ev.download_planes_raw(4)
+
+
+def test_team_trunk_192_channels(nsg, oracle, monkeypatch):
+    """The team trunk on a 192-channel net (BASELINE configs[1]'s width): twelve weight fragments, so teams of 72 / 36 /
+    24 / 12 workgroups per board, six of a member's eight waves with a K chunk.  Against the oracle, bit-identical
+    across team sizes' shared boards and from launch to launch, against the per-layer f16x3 kernels."""
+    ev, blob = make(nsg, 4, 192, 16, precision="f16m6", seed=520)
+    bb = nsg.synth.random_batch(16, 86, seed=521, garbage=True)
+    ref = oracle.net(blob).evaluate(bb)
+    cus = ev.info()["compute_units"]
+    outs = {}
+    for n in (16, 1, 3, 2, 5, 8, 9, 16, 1):
+        p, v, d = ev.compute_blocking(bb[:n])
+        plan, ts = ev.last_plan(), ev.team_stats()
+        assert plan["trunk_precision"] == "f16x3" and plan["waves_per_group"] == 8 and plan["k_split"] == 8, plan
+        want = next(12 * rg for rg in (6, 3, 2, 1) if n * 12 * rg <= cus)
+        assert ts["enabled"] == 1 and ts["members_last"] == want and ts["fallbacks"] == 0, (n, ts)
+        check((p, v, d), tuple(r[:n] for r in ref), 2e-4)
+        if n in outs:
+            np.testing.assert_array_equal(p, outs[n][0])
+            np.testing.assert_array_equal(v, outs[n][1])
+        outs[n] = (p, v, d)
+    np.testing.assert_array_equal(outs[9][0], outs[16][0][:9])  # the same team size: the same bits whatever else runs
+    for n in (1, 2, 3, 5, 8):  # other team sizes: the row groups only regroup independent row fragments
+        np.testing.assert_array_equal(outs[n][0], outs[16][0][:n])
+    monkeypatch.setenv("NSG_TEAM_TRUNK", "0")
+    old, _ = make(nsg, 4, 192, 16, precision="f16x3", seed=520)
+    po, vo, do = old.compute_blocking(bb)
+    assert old.last_plan()["waves_per_group"] != 8 and old.team_stats()["enabled"] == 0
+    assert float(np.abs(po - outs[16][0]).max()) < 1e-4 and float(np.abs(vo - outs[16][1]).max()) < 1e-4
+
+
+def test_team_sizes_and_member_override(nsg, monkeypatch):
+    """Workgroups per board follow what fits the device (every member must be resident at once); NSG_TEAM_MEMBERS
+    caps the row groups, is read per evaluator, and a value outside {16, 32, 48, 96} is refused."""
+    ev, _ = make(nsg, 2, 256, 16, precision="f16m6", seed=530)
+    cus = ev.info()["compute_units"]
+    bb = nsg.synth.random_batch(16, 86, seed=531)
+    ref = {}
+    for n in (1, 2, 3, 5, 6, 8, 9, 16):
+        ref[n] = ev.compute_blocking(bb[:n])
+        want = next(16 * rg for rg in (6, 3, 2, 1) if n * 16 * rg <= cus)
+        assert ev.team_stats()["members_last"] == want, (n, ev.team_stats())
+    monkeypatch.setenv("NSG_TEAM_MEMBERS", "32")
+    capped, _ = make(nsg, 2, 256, 16, precision="f16m6", seed=530)
+    for n in (1, 5, 9):
+        p, v, d = capped.compute_blocking(bb[:n])
+        assert capped.team_stats()["members_last"] == (32 if n * 32 <= cus else 16)
+        np.testing.assert_array_equal(p, ref[n][0])
+    monkeypatch.setenv("NSG_TEAM_MAX_BATCH", "4")
+    small, _ = make(nsg, 2, 256, 16, precision="f16m6", seed=530)
+    small.compute_blocking(bb[:4])
+    assert small.last_plan()["k_split"] == 8
+    small.compute_blocking(bb[:5])
+    assert small.last_plan()["k_split"] != 8
+
+
+@pytest.mark.parametrize("path", ["blocking", "resident", "gather"])
+def test_team_trunk_gives_up_and_the_batch_is_rerun(nsg, oracle, monkeypatch, path):
+    """A team launch whose members wait for each other in vain (here: the launch is made ONE WORKGROUP SHORT through the
+    test hook NSG_TEAM_FAULT_LAUNCHES; in the field: a device partition smaller than the grid, another process's
+    persistent kernel) gives up after its bounded spins.  The call that waits for it re-runs the SAME batch on the
+    per-layer kernels and succeeds -- nsg_await, and the device-resident read-backs too -- the evaluator keeps to those
+    kernels afterwards and counts the event."""
+    monkeypatch.setenv("NSG_TEAM_FAULT_LAUNCHES", "1")
+    ev, blob = make(nsg, 2, 256, 8, precision="f16m6", seed=540)
+    bb = nsg.synth.random_batch(8, 86, seed=541, garbage=True)
+    ref = oracle.net(blob).evaluate(bb)
+    assert ev.team_stats() == {"enabled": 1, "members_last": 0, "fallbacks": 0}
+    if path == "blocking":
+        out = ev.compute_blocking(bb[:5])
+        check(out, tuple(r[:5] for r in ref), 2e-4)
+    elif path == "resident":
+        ev.upload_features(bb[:5])
+        ev.forward_resident(5)
+        out = ev.download_outputs(5)
+        check(out, tuple(r[:5] for r in ref), 2e-4)
+    else:
+        rng = np.random.default_rng(3)
+        off = (np.arange(6) * 40).astype(np.uint32)
+        idx = rng.integers(0, 2187, size=200).astype(np.uint16)
+        vals = np.empty(200, np.float32)
+        win, draw = np.empty(5, np.float32), np.empty(5, np.float32)
+        ev.compute_gather_blocking(bb[:5], idx, off, softmax=False, values=vals, win=win, draw=draw)
+        want = np.concatenate([ref[0][b][idx[40 * b:40 * b + 40]] for b in range(5)])
+        assert float(np.abs(vals - want).max()) < 2e-4 and float(np.abs(win - ref[1][:5]).max()) < 2e-4
+    ts = ev.team_stats()
+    assert ts["fallbacks"] == 1 and ts["enabled"] == 0 and ts["members_last"] == 48, ts
+    assert ev.last_plan()["k_split"] != 8  # the re-run took the per-layer kernels
+    # ... and so does every later batch; the statistics count the batch once
+    p2, v2, d2 = ev.compute_blocking(bb)
+    check((p2, v2, d2), ref, 2e-4)
+    assert ev.last_plan()["k_split"] != 8 and ev.team_stats()["fallbacks"] == 1
+    assert ev.stats()["batches"] == 2
+
+
+def test_team_trunk_two_processes_one_device(nsg, tmp_path):
+    """Two PROCESSES on one GPU, each evaluating batches of at most sixteen boards: their team launches would hold
+    CUs the other's unscheduled members need.  One process owns the device's team token (an advisory file lock),
+    the other keeps to the per-layer kernels; both finish, neither pays a give-up, both agree with each other."""
+    import subprocess, sys, textwrap
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import importlib, json, os, sys, time
+        import numpy as np
+        sys.path.insert(0, sys.argv[1])
+        nsg = importlib.import_module("nshogi-engine_amd")
+        ev = nsg.Evaluator(0, 16, 86, precision="f16m6")
+        ev.load_memory(nsg.weights.to_blob(nsg.weights.make_random(3, 256, seed=550, bn="random")))
+        bb = nsg.synth.random_batch(16, 86, seed=551)
+        open(sys.argv[2] + ".ready", "w").close()
+        while not os.path.exists(sys.argv[3] + ".ready"):
+            time.sleep(0.01)
+        t0 = time.time()
+        acc = 0.0
+        for i in range(150):
+            n = 1 + (i * 7) % 16
+            p, v, d = ev.compute_blocking(bb[:n])
+            acc += float(p[0, :8].sum())
+        print(json.dumps({"team": ev.team_stats(), "first": ev.compute_blocking(bb[:3])[0][:, :4].tolist(),
+                          "seconds": time.time() - t0}))
+    """))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tags = [str(tmp_path / "a"), str(tmp_path / "b")]
+    # (this pytest process may itself hold the device's lock through evaluators not collected yet: the two workers
+    # coordinate through a lock directory of their own)
+    env = dict(os.environ, NSG_TEAM_LOCK_DIR=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, str(script), root, tags[i], tags[1 - i]], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for i in range(2)]
+    outs = []
+    for pr in procs:
+        so, se = pr.communicate(timeout=600)
+        assert pr.returncode == 0, se[-2000:]
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    enabled = sorted(o["team"]["enabled"] for o in outs)
+    assert enabled == [-1, 1], outs
+    assert all(o["team"]["fallbacks"] == 0 for o in outs), outs
+    # team trunk (f16x3 arithmetic) in one process, per-layer f16x3 small tiles in the other: the summation order differs
+    assert float(np.abs(np.array(outs[0]["first"]) - np.array(outs[1]["first"])).max()) < 1e-4
+
+
+@pytest.mark.parametrize("batch", [17, 30, 44, 64, 85])
+def test_f16m6_three_way_k_split_192_channels(nsg, oracle, monkeypatch, batch):
+    """192 channels are three chunk pairs: up to CUs/3 boards run one 64-channel group per workgroup whose three waves
+    take one pair each (all chunk tiles of the board resident in LDS), the rows over as many workgroups as fit one
+    round; the stem (two pairs) runs two-wave workgroups.  The MX arithmetic instead of the f16x3 small tiles these
+    batches ran before (NSG_KSPLIT3=0).  Against the oracle and the f16x3 evaluator."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    if batch * 3 > cus:
+        pytest.skip("batch range of this plan depends on the CU count")
+    ev, blob = make(nsg, 3, 192, batch, precision="f16m6", seed=560)
+    bb = nsg.synth.random_batch(batch, 86, seed=561, garbage=True)
+    p, v, d = ev.compute_blocking(bb)
+    plan = ev.last_plan()
+    assert plan["trunk_precision"] == "f16m6" and plan["k_split"] == 3 and plan["waves_per_group"] == 3, plan
+    assert plan["row_split"] == (6 if batch * 18 <= cus else 3 if batch * 9 <= cus else 2 if batch * 6 <= cus else 1)
+    idx = sorted({0, batch // 2, batch - 1})
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
+    x3, _ = make(nsg, 3, 192, batch, precision="f16x3", seed=560)
+    p3, v3, d3 = x3.compute_blocking(bb)
+    assert float(np.abs(p - p3).max()) < TOL and float(np.abs(v - v3).max()) < TOL
+    p2, v2, d2 = ev.compute_blocking(bb[::-1].copy())  # deterministic, slot-independent
+    np.testing.assert_array_equal(p2[::-1], p)
+    monkeypatch.setenv("NSG_KSPLIT3", "0")
+    old, _ = make(nsg, 3, 192, batch, precision="f16m6", seed=560)
+    po, vo, do = old.compute_blocking(bb)
+    assert old.last_plan()["k_split"] != 3
+    assert float(np.abs(p - po).max()) < TOL

@@ -288,6 +288,28 @@ def test_selfplay_hip_reproducible(nsg, tmp_path):
 
 
 @pytest.mark.gpu
+def test_selfplay_gumbel_mode_hip(nsg, tmp_path):
+    """--gumbel on the HIP evaluator (Gumbel AlphaZero root with sequential halving, worker.cc:428-475,784-905): the
+    policy logits the halving ranks now come from the network, not from the uniform stand-in executor.  Reproducible
+    from the seed, independent of the grouping of the game slots (a game's arithmetic depends on the batch's tile
+    plan only through bit-identical kernels: 64 channels, per-layer kernels), and different from the AlphaZero-mode
+    games of the same seed (the root selection rule changed, not just the noise)."""
+    path = tmp_path / "net.nsgw"
+    nsg.weights.save(str(path), nsg.weights.make_random(2, 64, seed=3, bn="random"))
+    base = ["--executor", "hip", "--weights", str(path), "--playouts", "32", "--num-sampling-moves", "16",
+            "--max-games", "4", "--seed", "9", "--threads", "1"]
+    la, lb, lc = tmp_path / "a.log", tmp_path / "b.log", tmp_path / "c.log"
+    a = json.loads(run("selfplay", *base, "--gumbel", "1", "--games-per-group", "6", "--game-log", la))
+    b = json.loads(run("selfplay", *base, "--gumbel", "1", "--games-per-group", "6", "--game-log", lb))
+    assert a["games_finished"] >= 4 and a["digest"] == b["digest"] and a["moves"] == b["moves"]
+    assert a["evals_per_sec"] > 0 and a["playouts_per_sec"] > 0
+    c = json.loads(run("selfplay", *base, "--gumbel", "0", "--games-per-group", "6", "--game-log", lc))
+    ga, gc = _game_log(la), _game_log(lc)
+    common = set(ga) & set(gc)
+    assert common and any(ga[g] != gc[g] for g in common)
+
+
+@pytest.mark.gpu
 def test_selfplay_team_trunk_two_engine_threads_reproducible(nsg, tmp_path):
     """Small leaf batches of a 256-channel net run the team trunk (one persistent launch per forward, one such launch
     per device at a time).  Two engine threads = four evaluators hand the device's token to each other all the time:
