@@ -473,6 +473,11 @@ def main():
                     help="length of the second self-play leg in the shape whose move digests reproduce bit for bit "
                          "(one search worker, no solver pool: north_star's fixed-seed determinism); 0 disables it")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the by_config legs (configs[1], configs[4])")
+    ap.add_argument("--workload-only", type=int, default=0, metavar="N",
+                    help="profiler workload: load, upload, N device-resident steps of the benchmark's batch, one read-back, "
+                         "exit -- no HIP events, no child processes, no other legs (scripts/pmc.sh runs rocprofv3 --pmc "
+                         "passes over this; add --hip-events to bracket the launches with events as the timed run does)")
+    ap.add_argument("--hip-events", action="store_true", help="with --workload-only: enable the HIP-event timing too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-sample", action="store_true",
                     help="no rocm-smi child processes during the sustained leg (under rocprofv3 the box refuses a "
@@ -544,6 +549,20 @@ def main():
 
     bb = positions(args.positions)
     ev.upload_features(bb)
+    if args.workload_only > 0:
+        if args.hip_events:
+            ev.profile_enable(True)
+        for _ in range(args.workload_only):
+            ev.forward_resident(B)
+        p, v, d = ev.download_outputs(B)
+        if args.hip_events:
+            print(json.dumps(ev.profile_read()))
+        print(json.dumps({"workload_only": args.workload_only, "batch": B, "net": args.net, "precision": args.precision,
+                          "policy_max": float(p.max()), "value0": float(v[0]), "plan": ev.last_plan()}))
+        ev.close()
+        if distributed:
+            dist.destroy_process_group()
+        return
 
     def barrier():
         if distributed:

@@ -207,11 +207,21 @@ __global__ __launch_bounds__(kThreadsM6) void extractActM6(
     typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
     typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) uint4 sBoard[];
+    // [channels] bitboards, then the staging image of one round of rows: kThreadsM6 x 8 pieces of 16 bytes.  A thread's
+    // row is 128 contiguous bytes of memory, so written from its registers every store instruction touches 64 lines
+    // for 16 bytes each (measured 1.5 TB/s, 0.18 of the HBM roof: profiles/r03).  The rows go through LDS instead --
+    // piece p of thread t at slot 8 t + (p ^ ((t >> 1) & 7)): sixteen consecutive threads writing one p hit sixteen
+    // different 16-byte slots of the 256-byte bank row -- and leave lane-linearly: instruction j of thread u moves piece
+    // j * kThreadsM6 + u of the round, 1 KiB of whole lines per wave instruction.
+    uint4* stage = sBoard + ((channels + 7) / 8) * 8;
     const int b = blockIdx.x;
     for (int c = threadIdx.x; c < channels; c += kThreadsM6) sBoard[c] = src[(size_t)b * channels + c];
     __syncthreads();
     const int chunks = cpad / 32;
-    for (int it = threadIdx.x; it < 81 * chunks; it += kThreadsM6) {
+    const int items = 81 * chunks;
+    for (int it0 = 0; it0 < items; it0 += kThreadsM6) {
+        const int it = it0 + threadIdx.x;
+        if (it < items) {
         const int sq = it / chunks, kc = it - sq * chunks;
         uint32_t hp[16], lp[16];
         u16x2 mh = {0, 0}, ml = {0, 0}; // running maxima of |hi|, |lo| as f16 bit patterns (order-preserving)
@@ -244,13 +254,26 @@ __global__ __launch_bounds__(kThreadsM6) void extractActM6(
         u32x6 hb, lb; // (early clobber: the builtin may place the result inside its source, mfma_tile.h)
         asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(hb) : "v"(hsrc), "v"(__uint_as_float(eh << 23)));
         asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(lb) : "v"(lsrc), "v"(__uint_as_float(el << 23)));
-        uint4* row = reinterpret_cast<uint4*>(dst + ((size_t)b * 81 + sq) * cpad * 4 + (size_t)kc * 128);
+        const int t = threadIdx.x, sw = (t >> 1) & 7;
+        uint4* row = stage + t * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) row[i] = make_uint4(hp[4 * i], hp[4 * i + 1], hp[4 * i + 2], hp[4 * i + 3]);
-        row[4] = make_uint4(hb.s0, hb.s1, hb.s2, hb.s3);
-        row[5] = make_uint4(hb.s4, hb.s5, eh, 0u);
-        row[6] = make_uint4(lb.s0, lb.s1, lb.s2, lb.s3);
-        row[7] = make_uint4(lb.s4, lb.s5, el, 0u);
+        for (int i = 0; i < 4; ++i) row[i ^ sw] = make_uint4(hp[4 * i], hp[4 * i + 1], hp[4 * i + 2], hp[4 * i + 3]);
+        row[4 ^ sw] = make_uint4(hb.s0, hb.s1, hb.s2, hb.s3);
+        row[5 ^ sw] = make_uint4(hb.s4, hb.s5, eh, eh); // (the exponent twice: bytes 24 and 28 of the block, kernels.h)
+        row[6 ^ sw] = make_uint4(lb.s0, lb.s1, lb.s2, lb.s3);
+        row[7 ^ sw] = make_uint4(lb.s4, lb.s5, el, el);
+        }
+        __syncthreads();
+        // the round's rows are contiguous in memory: items it0 .. it0 + n - 1 = n x 128 bytes from there on
+        const int n = items - it0 < kThreadsM6 ? items - it0 : kThreadsM6;
+        uint4* out = reinterpret_cast<uint4*>(dst + ((size_t)b * 81 * cpad * 4) + (size_t)it0 * 128);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int piece = j * kThreadsM6 + threadIdx.x; // of the round, in memory order
+            const int t = piece >> 3, p = piece & 7;
+            if (t < n) out[piece] = stage[t * 8 + (p ^ ((t >> 1) & 7))];
+        }
+        __syncthreads();
     }
 }
 
@@ -319,7 +342,8 @@ hipError_t launchExtractBitsAct(void* dst, const uint64_t* src, int batch,
                            stream, dst, (const uint4*)src, channels, cpad);
     } else if (prec == kF16m6) {
         if (cpad % 32 != 0) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(extractActM6, dim3(batch), dim3(kThreadsM6), smem,
+        const size_t smemM6 = (size_t)((channels + 7) / 8 * 8 + kThreadsM6 * 8) * sizeof(uint4); // bitboards + one round of rows
+        hipLaunchKernelGGL(extractActM6, dim3(batch), dim3(kThreadsM6), smemM6,
                            stream, (unsigned char*)dst, (const uint4*)src, channels, cpad);
     } else {
         hipLaunchKernelGGL(extractAct<kBf16>, dim3(batch), dim3(kThreads), smem,

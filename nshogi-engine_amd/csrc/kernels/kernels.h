@@ -33,8 +33,10 @@ namespace nsg {
 // retires its K = 128 in the cycles of ONE f16 MFMA (half the e4m3 form:
 // profiles/r02/a_fp6_probe.txt): 1.5 MFMA units per MAC.  No fixed scales, hence no clamp
 // window: the block exponent follows the data.  Activations: 128-byte chunks of 32 channels,
-// [32 x f16 hi][24 B: e2m3(hi), channel order 0..31][1 B E8M0][7 B pad]
-//              [24 B: e2m3(lo), channel order 0..31][1 B E8M0][7 B pad]
+// [32 x f16 hi][24 B: e2m3(hi), channel order 0..31][1 B E8M0][3 B 0][1 B E8M0 again][3 B 0]
+//              [24 B: e2m3(lo), channel order 0..31][1 B E8M0][3 B 0][1 B E8M0 again][3 B 0]
+// (the exponent sits in both trailing dwords of a block: the conv's main loop reads the codes as 16 + 8 bytes and the
+// exponent as the block's last dword, mfma_tile.h kSplitRead)
 enum Precision { kFp32 = 0, kFp16 = 1, kBf16 = 2, kF16x3 = 3, kF16m8 = 4, kF16m6 = 5 };
 // the two split-precision trunk formats that run their correction terms on the MX instruction
 constexpr bool isMx(int prec) { return prec == kF16m8 || prec == kF16m6; }

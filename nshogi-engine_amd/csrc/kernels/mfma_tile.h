@@ -420,7 +420,7 @@ struct StepSeq {
     static constexpr int kMax = (27 * MF + WIN - 1) / WIN * WIN;
     struct Tab {
         int n, padded;
-        short pos[kMax], frag[kMax], index[27 * MF];
+        short pos[kMax], frag[kMax], index[27 * MF], xord[kMax];
     };
     static constexpr bool active(int u, int f) { return !PERM || EdgeRows::needTap(f, OS::slab(u) / 3); }
     static constexpr Tab make() {
@@ -438,6 +438,11 @@ struct StepSeq {
         t.n = n;
         t.padded = (n + WIN - 1) / WIN * WIN;
         for (int q = n; q < kMax; ++q) { t.pos[q] = 0; t.frag[q] = -1; }
+        int nx = 0; // MX steps (slab % 3 == 2) in front of step q
+        for (int q = 0; q < kMax; ++q) {
+            t.xord[q] = (short)nx;
+            if (q < n && OS::slab(t.pos[q]) % 3 == 2) ++nx;
+        }
         return t;
     }
     static constexpr Tab kTab = make();
@@ -446,6 +451,7 @@ struct StepSeq {
     static constexpr int pos(int q) { return kTab.pos[q]; }
     static constexpr int frag(int q) { return kTab.frag[q]; } // -1: null step
     static constexpr int index(int u, int f) { return kTab.index[u * MF + f]; }
+    static constexpr int xord(int q) { return kTab.xord[q]; } // ordinal of MX step q among the pair's MX steps
 };
 
 // One layer's work for this workgroup.  RES: 0 = no residual, 1 = residual,
@@ -633,10 +639,10 @@ _Pragma("unroll") \
         using OS = OwnSeq<SS, PART>; // the slabs of a pair this wave runs, in its own order (SS = 1: all 27)
         static_assert(G::kTaps == 9, "3x3 taps");
         constexpr int kWin = 9, kD = 7; // (five or eight steps of lead: +-0.5 %, profiles/r03/README.md)
-#ifdef NSG_SPREAD_LOADS // A/B build (make ab ABFLAGS=-DNSG_SPREAD_LOADS)
-        constexpr bool kSpread = kMFw > NFRAG; // (fragments 0 .. NFRAG run every tap, edge-packed rows or not)
-#else
+#ifdef NSG_NO_SPREAD_LOADS // A/B partner build (make ab ABFLAGS=-DNSG_NO_SPREAD_LOADS): a slab's requests behind its first MFMA
         constexpr bool kSpread = false;
+#else
+        constexpr bool kSpread = kMFw > NFRAG; // (fragments 0 .. NFRAG run every tap, edge-packed rows or not)
 #endif
         using ST = StepSeq<OS, kMFw, kPerm, kWin>;
         constexpr int kReal = ST::kReal;   // (own slab, fragment) steps that issue MFMAs
@@ -721,7 +727,19 @@ _Pragma("unroll") \
         }
         NSG_STAMP(1);
 
-        u32x4 aw[kWin][2];
+        // Opt-in (make ab ABFLAGS=-DNSG_MX_SPLIT_READ), MEASURED SLOWER: -3 % at 512 boards, -4 % at 1024, +-0.5 % at 32-256
+        // (profiles/r04/d_ab_split_mx_operand_read_and_spread_requests.txt).  It removes every copy in front of the MX
+        // steps (88 v_accvgpr_write + 80 s_nop per chunk pair, see below) and the SS = 2 / 4 kernels' spills, but its
+        // 8- and 4-byte reads walk the image at its 16-byte entry stride: 4-way bank conflicts, where the 16-byte reads
+        // have none or two -- the LDS, not the issue port, is what the two-board tiles' MX slabs wait for.
+#ifdef NSG_MX_SPLIT_READ
+        constexpr bool kSplitRead = kM6 && OS::kX > 0;
+#else
+        constexpr bool kSplitRead = false;
+#endif
+        u32x4 aw[kWin][kSplitRead ? 1 : 2];
+        [[maybe_unused]] u32x2 aw45[kSplitRead ? kWin : 1];
+        [[maybe_unused]] uint32_t awS[kSplitRead ? kWin : 1];
         // fragment request of step q (q >= kSteps: the next pair's step q - kSteps; null steps request nothing)
 #define NSG_M8_REQ(QQ, CUR, NXT)                                                                  \
         if (ST::frag((QQ) % kSteps) >= 0) {                                                       \
@@ -731,7 +749,12 @@ _Pragma("unroll") \
             if (Q::isX(s_)) {                                                                     \
                 const unsigned char* ap_ = b_ + abase[f_] + offp8 + tapOff(Q::tap(s_));           \
                 aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(ap_);                        \
-                aw[(QQ) % kWin][1] = *reinterpret_cast<const u32x4*>(ap_ + G::kPlane);            \
+                if constexpr (kSplitRead) {                                                       \
+                    aw45[(QQ) % kWin] = *reinterpret_cast<const u32x2*>(ap_ + G::kPlane);         \
+                    awS[(QQ) % kWin] = *reinterpret_cast<const uint32_t*>(ap_ + G::kPlane + 12);   \
+                } else {                                                                          \
+                    aw[(QQ) % kWin][kSplitRead ? 0 : 1] = *reinterpret_cast<const u32x4*>(ap_ + G::kPlane); \
+                }                                                                                 \
             } else {                                                                              \
                 aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(                             \
                     b_ + Q::half(s_) * G::kBuf + abase[f_] + tapOff(Q::tap(s_)));                 \
@@ -816,8 +839,20 @@ _Pragma("unroll") \
                     NSG_M8_REQ(q + kD, abuf, nbuf)
                     const int slot = q % kWin;
                     if (Q::isX(s)) {
-                        const i32x8 xb = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, aw[slot][0]),
-                                                                 __builtin_bit_cast(i32x4_t, aw[slot][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+                        // kSplitRead: the operand's six data dwords arrive as a 16-byte and an 8-byte read -- both
+                        // wholly inside the six-register operand, so they land in place -- and the block's exponent
+                        // as a third, 4-byte read of the block's LAST dword (the exponent is stored twice, at bytes
+                        // 24 and 28: a read of byte 24 is adjacent to the 8-byte one and the compiler fuses the two
+                        // into one 12-byte read again).  Two 16-byte reads leave the second one half data, half
+                        // exponent: under register pressure its data half was copied into place -- two moves and
+                        // the wait states between a vector write and the MFMA that reads it, in front of EVERY MX
+                        // step's first MFMA (88 moves + 80 s_nop per chunk pair, gone; profiles/r04/README.md).
+                        i32x8 xb;
+                        if constexpr (kSplitRead)
+                            xb = i32x8{(int)aw[slot][0].x, (int)aw[slot][0].y, (int)aw[slot][0].z, (int)aw[slot][0].w,
+                                       (int)aw45[slot].x, (int)aw45[slot].y, (int)awS[slot], 0};
+                        else xb = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, aw[slot][0]),
+                                                          __builtin_bit_cast(i32x4_t, aw[slot][1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                         for (int j = 0; j < NFRAG; ++j) {
                             const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[xj & 1][j][0]),
@@ -838,7 +873,7 @@ _Pragma("unroll") \
                     // shadow instead of between two steps), then the other MFMAs
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     if (ST::frag((q + kD) % kSteps) >= 0) {
-                        if (Q::isX(OS::slab(ST::pos((q + kD) % kSteps)))) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        if (Q::isX(OS::slab(ST::pos((q + kD) % kSteps)))) __builtin_amdgcn_sched_group_barrier(0x100, kSplitRead ? 3 : 2, 0);
                         else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                     if ((kSpread ? f < NFRAG : f == 0) && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, kSpread ? 1 : NFRAG, 0);
@@ -1521,7 +1556,7 @@ _Pragma("unroll") \
                         const float sc = __uint_as_float(e8 << 23);
                         asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(blk) : "v"(src), "v"(sc));
                         op[2] = u32x4{blk.s0, blk.s1, blk.s2, blk.s3};
-                        op[3] = u32x4{blk.s4, blk.s5, e8, 0u};
+                        op[3] = u32x4{blk.s4, blk.s5, e8, e8}; // (the exponent twice: the consumer's split read, kSplitRead)
                     } else {
                         // two values per instruction where the ISA has a packed form (v_cvt_pk_f16_f32,
                         // v_pk_add_f32, v_pk_mul_f32); v_med3 needs no NaN-quieting of its inputs

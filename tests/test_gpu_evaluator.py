@@ -311,7 +311,7 @@ def _e2m3_codes(x):
 
 def test_f16m6_trunk_input_encoding(nsg, oracle):
     """The plane expansion of an f16m6 evaluator, byte for byte: per (square, 32-channel chunk) a
-    128-byte row [32 x f16 hi][24 B e2m3(hi) + E8M0 exponent][24 B e2m3(lo) + exponent], value j of a
+    128-byte row [32 x f16 hi][24 B e2m3(hi) + E8M0 exponent, stored in both trailing dwords][24 B e2m3(lo) + exponent], value j of a
     block at bits [6j, 6j+6), exponent = that of the block maximum minus 2 (zero block: 2^-17, codes
     0).  Inputs: real plane bits plus scalar planes with values all over [0, 1]."""
     B = 70  # an MX plan (two-board tiles need > CUs/4 boards)
@@ -333,7 +333,7 @@ def test_f16m6_trunk_input_encoding(nsg, oracle):
     for name, off, vals in (("hi", 64, want_hi), ("lo", 96, want_lo)):
         blk = rows[..., off:off + 32]
         e8 = blk[..., 24].astype(np.int64)
-        assert (blk[..., 25:32] == 0).all()
+        assert (blk[..., 25:28] == 0).all() and (blk[..., 28] == blk[..., 24]).all() and (blk[..., 29:32] == 0).all()
         mx = np.abs(vals.astype(np.float64)).max(axis=-1)
         bits = np.abs(vals).max(axis=-1).astype(np.float16).view(np.uint16).astype(np.int64)
         np.testing.assert_array_equal(e8, (bits >> 10) + 110, err_msg=name)
