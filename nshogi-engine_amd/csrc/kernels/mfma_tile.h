@@ -537,6 +537,21 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         if (grow > lastRow) grow = lastRow;
         srcOff[k] = grow * (size_t)A.kdim * ES + ((wid & 1) * 4 + g) * 16 + (size_t)kc0 * 128;
     }
+    // MX conv tiles read their input through a buffer descriptor on the workgroup's own boards: a 32-bit lane offset
+    // inside the tile + a wave-uniform chunk offset, instead of a 64-bit address per item (the loop has no vector
+    // registers to spare for address pairs, and no issue slots for their 64-bit adds)
+    constexpr bool kTileBuf = isMx(PREC) && MODE == kConv;
+    [[maybe_unused]] int srcRel[G::kItems];
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t xrs;
+    if constexpr (kTileBuf) {
+        xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(A.x) + row0 * (size_t)A.kdim * ES, 0, 0x7fffffff, 0x00027000);
+#pragma unroll
+        for (int k = 0; k < G::kItems; ++k) srcRel[k] = (int)(srcOff[k] - row0 * (size_t)A.kdim * ES);
+    }
+    auto tileLoad = [&](int k, int chunk) -> u32x4 { // item k of channel chunk `chunk` (wave-uniform)
+        if constexpr (kTileBuf) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, srcRel[k], chunk * 128, 0));
+        else return *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)chunk * 128);
+    };
     u32x4 st[G::kItems];
     // K-split tiles (every chunk tile of the board resident): the tile loads go out FIRST, before the
     // per-lane tables, the weight pointers and the first weight records are set up -- the prologue of these
@@ -551,7 +566,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
             for (int k = 0; k < G::kItems; ++k) {
                 stAll[c][k] = u32x4{0u, 0u, 0u, 0u};
-                if (__builtin_expect(c < nkc, 1)) stAll[c][k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)c * 128);
+                if (__builtin_expect(c < nkc, 1)) stAll[c][k] = tileLoad(k, c);
             }
         __builtin_amdgcn_sched_barrier(0);
         NSG_STAMP(4); // (diagnostic builds) every tile load issued
@@ -671,37 +686,73 @@ _Pragma("unroll") \
         auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
         // MX operand of lane (li, g): 32 fp8 bytes of chunk g>>1 (A / B buffer); g&1 ? lo bytes : hi bytes
         const int offp8 = (g >> 1) * G::kBuf + (4 + 2 * (g & 1) - g) * G::kPlane;
-        const size_t rs = (size_t)nft * 64; // one record set
+        // Weight records of a chunk pair, per tap: [main A: nft KiB][main B: nft KiB][MX slab].  kF16m8: the MX slab is
+        // two 1-KiB records per fragment (32 fp8 bytes per lane).  kF16m6 (kPackX): per group of four fragments
+        // [4 x 1 KiB: code dwords 0-3][4 x 512 B: code dwords 4-5][256 B: one dword per lane = the four fragments'
+        // E8M0 exponents, byte j for fragment j (the instruction's op_sel picks it)] = 100 bytes per lane instead of
+        // 128: the padding behind every 24-byte block and its exponent byte made up 11 % of a layer's weight bytes,
+        // and the one-board tiles of the mid batches run at the rate their CU's L1 streams weights (1.18 MB per layer
+        // and workgroup at 128 boards = 18k cycles at 64 B/clk against 20.7k cycles of MFMAs).
+        constexpr bool kPackX = kM6;
+        const int mainSet = nft * 1024, xSet = nft * (kPackX ? 1600 : 2048);
+        const int tapStride = 2 * mainSet + xSet, pairStride = G::kTaps * tapStride;
+        // (tapS / mainS: the same two numbers, made opaque at the top of every pair so that the ~40 slab offsets
+        // built from them are computed where they are used -- two scalar instructions -- instead of being hoisted
+        // out of the pair loop into scalar registers the loop does not have: the K-split kernels spilled them to
+        // vector lanes, 120 v_readlane + their wait states per pair)
+        int tapS = tapStride, mainS = mainSet;
+        auto mainOff = [&](int s) { return (s / 3) * tapS + (s % 3) * mainS; }; // s % 3 in {0, 1}
+        auto xOff = [&](int s) { return (s / 3) * tapS + 2 * mainS; };
         constexpr bool kStage = (KS == 1); // KS > 1: every chunk tile is resident, nothing is staged in the loop
         const int kpart = (KS > 1) ? wave % KS : 0; // this wave's share of the chunk pairs
         const int npairs = nkc / 2 / KS; // pairs this wave runs (the host pads the input channels to whole pairs)
         const int pair0 = kpart * npairs;  // K split: a contiguous range of the pairs
-        const u32x4* wc = A.w + lane + (size_t)pair0 * Q::kRecPair * rs;
-        const size_t wg4 = (size_t)waveGroup * NFRAG * 64;  // this wave's records inside a main set
-        const size_t wg8 = wg4 * 2;                         //                          an MX pair of sets
+        // The records are read through a buffer descriptor: wave-uniform byte offset (scalar registers and the
+        // instruction's immediate) + one 32-bit lane offset that never changes, instead of a 64-bit per-lane address
+        // per request (a v_lshl_add_u64 each, and the address pairs live in vector registers this loop does not have).
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(A.w), 0, 0x7fffffff, 0x00027000);
+        int wc = pair0 * pairStride;                                      // byte offset of the current pair's records
+        const int wg4 = waveGroup * NFRAG * 1024;                         // this wave's fragments inside a main set
+        const int wg8 = kPackX ? waveGroup * 6400 : waveGroup * NFRAG * 2048; // ... inside an MX slab
+        const int lane16 = lane * 16, lane8 = lane * 8, lane4 = lane * 4;
+        // (off_: wave-uniform, one scalar register per slab; imm_: a constant below 4096 that rides in the instruction)
+        auto ld16 = [&](int off_, int imm_) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + imm_, off_, 0)); };
+        auto ld8 = [&](int off_, int imm_) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane8 + imm_, off_, 0)); };
+        auto ld4 = [&](int off_, int imm_) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane4 + imm_, off_, 0); };
         // weight registers: three sets of f16 records (own main slab o in set o % 3, requested two own main
         // slabs ahead), two sets of MX records (own MX slab j in set j & 1)
         u32x4 w4[OS::kMain > 0 ? 3 : 1][NFRAG];
-        u32x4 w8[OS::kX > 0 ? 2 : 1][NFRAG][2];
+        u32x4 w8[OS::kX > 0 ? 2 : 1][NFRAG][kPackX ? 1 : 2]; // code dwords 0-3 (kF16m8: both halves of the 32 bytes)
+        [[maybe_unused]] u32x2 w8b[OS::kX > 0 ? 2 : 1][NFRAG];    // kPackX: code dwords 4-5
+        [[maybe_unused]] uint32_t w8s[OS::kX > 0 ? 2 : 1];        // kPackX: the four fragments' exponents
+        // MX records of own slab `S_` (byte offset OFF_ from wc) into set SET_: fragment J_ only, or all (J_ < 0)
+#define NSG_M8_LOADX(SET_, OFF_, J_)                                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < NFRAG; ++j_) {                                                  \
+            if ((J_) >= 0 && j_ != (J_)) continue;                                                              \
+            if constexpr (kPackX) {                                                                             \
+                w8[SET_][j_][0] = ld16(wc + (OFF_) + wg8, j_ * 1024);                                           \
+                w8b[SET_][j_] = ld8(wc + (OFF_) + wg8 + 4096, j_ * 512);                                        \
+                if ((J_) < 0 ? j_ == 0 : (J_) == 0) w8s[SET_] = ld4(wc + (OFF_) + wg8 + 4096, 2048);            \
+            } else {                                                                                            \
+                _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                \
+                    w8[SET_][j_][kPackX ? 0 : h_] = ld16(wc + (OFF_) + wg8 + (j_ >> 1) * 4096, ((j_ & 1) * 2 + h_) * 1024); \
+            }                                                                                                   \
+        }
         if constexpr (OS::kMain > 0) {
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
-                for (int j = 0; j < NFRAG; ++j) w4[o][j] = wc[Q::recOff(OS::mainSlab(o)) * rs + wg4 + j * 64];
+                for (int j = 0; j < NFRAG; ++j) w4[o][j] = ld16(wc + mainOff(OS::mainSlab(o)) + wg4, j * 1024);
         }
-        if constexpr (OS::kXCyclic) {
-#pragma unroll
-            for (int j = 0; j < NFRAG; ++j)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) w8[0][j][h] = wc[Q::recOff(OS::xSlab(0)) * rs + wg8 + (j * 2 + h) * 64];
-        }
+        if constexpr (OS::kXCyclic) { NSG_M8_LOADX(0, xOff(OS::xSlab(0)), -1) }
 
         if constexpr (kStage) {
         // first pair's tiles: both requested up front (the loop's operand registers are not live yet)
         u32x4 st1[G::kItems];
-        NSG_STAGE_LOAD(0)
 #pragma unroll
-        for (int k = 0; k < G::kItems; ++k) st1[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + 128);
+        for (int k = 0; k < G::kItems; ++k) st[k] = tileLoad(k, 0);
+#pragma unroll
+        for (int k = 0; k < G::kItems; ++k) st1[k] = tileLoad(k, 1);
         NSG_STAMP(4);
         if constexpr (kPerm) { NSG_COMPUTE_ABASE }
         if (zeroLds) zeroHalo<G>(smem, tid);
@@ -775,7 +826,8 @@ _Pragma("unroll") \
             [[maybe_unused]] const int nextA = (kp + 1 < npairs) ? 2 * kp + 2 : 2 * kp; // (last pair: harmless re-load)
             // records of the NEXT pair (the last pair re-reads its own: the buffer's zero padding covers two
             // record sets past the end, not a whole pair)
-            [[maybe_unused]] const size_t nextRec = (SS == 1 || kp + 1 < npairs) ? (size_t)Q::kRecPair : 0;
+            [[maybe_unused]] const int nextRec = (SS == 1 || kp + 1 < npairs) ? pairStride : 0;
+            asm volatile("" : "+s"(tapS), "+s"(mainS));
             NSG_PIN_ACC_AGPR
 #pragma unroll
             for (int u = 0; u < kOwn; ++u) {
@@ -806,19 +858,15 @@ _Pragma("unroll") \
                     if (kSpread ? f < NFRAG : f == 0) {
                         if (!Q::isX(s)) { // f16 record two own main slabs ahead (beyond this pair: the next pair's)
                             const int o2 = OS::mainOrd(u) + 2;
-                            const size_t o = (o2 >= OS::kMain ? nextRec : 0) + Q::recOff(OS::mainSlab(o2 % (OS::kMain > 0 ? OS::kMain : 1)));
+                            const int o = (o2 >= OS::kMain ? nextRec : 0) + mainOff(OS::mainSlab(o2 % (OS::kMain > 0 ? OS::kMain : 1)));
 #pragma unroll
                             for (int j = 0; j < NFRAG; ++j)
-                                if (!kSpread || j == f) w4[o2 % 3][j] = wc[o * rs + wg4 + j * 64];
+                                if (!kSpread || j == f) w4[o2 % 3][j] = ld16(wc + o + wg4, j * 1024);
                         }
                         if (reqX) {
                             const int j2 = OS::kXCyclic ? xj + 1 : ((u == 0 && xj != 0) ? 0 : xj + 1);
-                            const size_t o = ((OS::kXCyclic && j2 >= OS::kX) ? nextRec : 0) + Q::recOff(OS::xSlab(j2 % (OS::kX > 0 ? OS::kX : 1)));
-#pragma unroll
-                            for (int j = 0; j < NFRAG; ++j)
-#pragma unroll
-                                for (int h = 0; h < 2; ++h)
-                                    if (!kSpread || j == f) w8[j2 & 1][j][h] = wc[o * rs + wg8 + (j * 2 + h) * 64];
+                            const int o = ((OS::kXCyclic && j2 >= OS::kX) ? nextRec : 0) + xOff(OS::xSlab(j2 % (OS::kX > 0 ? OS::kX : 1)));
+                            NSG_M8_LOADX(j2 & 1, o, (kSpread ? f : -1))
                         }
                     }
                     const bool loadA = kStage && f == fTile && u >= kLoadSlabA && u < kLoadSlabA + kLoadSlabs;
@@ -830,7 +878,7 @@ _Pragma("unroll") \
                             if (A.exp & 4) st[k] = *reinterpret_cast<const u32x4*>(A.x + lane * 16);
                             else
 #endif
-                            st[k] = *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)(nextA + (loadB ? 1 : 0)) * 128);
+                            st[k] = tileLoad(k, nextA + (loadB ? 1 : 0));
                     }
                     if (q == 0) {
 #pragma unroll
@@ -855,13 +903,23 @@ _Pragma("unroll") \
                                                           __builtin_bit_cast(i32x4_t, aw[slot][1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                         for (int j = 0; j < NFRAG; ++j) {
-                            const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[xj & 1][j][0]),
-                                                                     __builtin_bit_cast(i32x4_t, w8[xj & 1][j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
-                            if constexpr (kM6) // e2m3 x e2m3; dword 6 of either operand block carries its E8M0 exponent in byte 0
-                                acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 2, 2, 0, wa[6], 0, xb[6]);
-                            else
+                            if constexpr (kPackX) {
+                                // e2m3 x e2m3: the weight block's E8M0 exponent is byte j of the slab's exponent dword
+                                // (op_sel: an immediate), the row block's is byte 0 of dword 6 of its 32 bytes
+                                const u32x4 a03 = w8[xj & 1][j][0];
+                                const u32x2 a45 = w8b[xj & 1][j];
+                                const i32x8 wa = {(int)a03.x, (int)a03.y, (int)a03.z, (int)a03.w, (int)a45.x, (int)a45.y, 0, 0};
+                                const int sc = (int)w8s[xj & 1];
+                                if (j == 0) acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 2, 2, 0, sc, 0, xb[6]);
+                                else if (j == 1) acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 2, 2, 1, sc, 0, xb[6]);
+                                else if (j == 2) acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 2, 2, 2, sc, 0, xb[6]);
+                                else acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 2, 2, 3, sc, 0, xb[6]);
+                            } else {
+                                const i32x8 wa = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w8[xj & 1][j][0]),
+                                                                         __builtin_bit_cast(i32x4_t, w8[xj & 1][j][kPackX ? 0 : 1]), 0, 1, 2, 3, 4, 5, 6, 7);
                                 acc[f][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[f][j], 0, 0, 0,
                                                                                             kM8ScaleByte, 0, 127);
+                            }
                         }
                     } else {
 #pragma unroll
@@ -877,15 +935,19 @@ _Pragma("unroll") \
                         else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                     if ((kSpread ? f < NFRAG : f == 0) && !Q::isX(s)) __builtin_amdgcn_sched_group_barrier(0x020, kSpread ? 1 : NFRAG, 0);
-                    if ((kSpread ? f < NFRAG : f == 0) && reqX) __builtin_amdgcn_sched_group_barrier(0x020, kSpread ? 2 : 2 * NFRAG, 0);
+                    if ((kSpread ? f < NFRAG : f == 0) && reqX) {
+                        if (kPackX && f == 0) __builtin_amdgcn_sched_group_barrier(0x020, (kSpread ? 2 : 2 * NFRAG) + 1, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x020, kSpread ? 2 : 2 * NFRAG, 0);
+                    }
                     if (loadA || loadB) __builtin_amdgcn_sched_group_barrier(0x020, (G::kItems + kLoadSlabs - 1) / kLoadSlabs, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NFRAG - 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            wc += (size_t)Q::kRecPair * rs;
+            wc += pairStride;
         }
 #undef NSG_M8_REQ
+#undef NSG_M8_LOADX
         __syncthreads(); // every wave is done reading before the epilogue reuses LDS
         if constexpr (KS > 1) {
             // Sum the K parts: every wave publishes its accumulators, then keeps the row fragments

@@ -329,7 +329,10 @@ static inline uint16_t hostF32ToBf16(float f) {
 
 size_t tileWeightRecords(int taps, int kdim, int cout, int prec) {
     const int nkc = kdim / chunkChannels(prec);
-    return ((size_t)nkc * recordsPerChunk(taps, prec) + 16) * (cout / 16) * 64; // + 16 zero records: deepest prefetch
+    const size_t nft = (size_t)(cout / 16);
+    if (prec == kF16m6) // packed MX slabs: per tap and chunk pair nft x (1024 + 1024 + 1600) bytes (mfma_tile.h, kPackX)
+        return (size_t)(nkc / 2) * taps * nft * 3648 / 16 + 16 * nft * 64;
+    return ((size_t)nkc * recordsPerChunk(taps, prec) + 16) * nft * 64; // + 16 zero records: deepest prefetch
 }
 
 namespace {
@@ -404,28 +407,30 @@ void packTileWeightsM8(WeightGetter get, const void* ctx, int taps, int kReal, i
                        float scale, unsigned char* out, bool fp6) {
     const int npairs = kdim / 64;
     const int nft = cout / 16;
-    const size_t recBytes = (size_t)nft * 64 * 16; // one record set: nft fragments x 64 lanes x 16 B
+    // per tap: [main A: nft KiB][main B: nft KiB][MX slab: kF16m8 2 nft KiB; kF16m6 nft/4 groups of 6400 bytes =
+    // 4 x 1 KiB code dwords 0-3, 4 x 512 B code dwords 4-5, 256 B exponent dwords (byte j = fragment j of the group)]
+    const size_t mainSet = (size_t)nft * 1024, xSet = (size_t)nft * (fp6 ? 1600 : 2048), tapStride = 2 * mainSet + xSet;
     auto chan = [](int nf, int rho) {
         return (nf / kNfrag) * kNfrag * 16 + (rho >> 2) * 4 * kNfrag + (nf % kNfrag) * 4 + (rho & 3);
     };
     auto wval = [&](int n, int k, int t) { return (k < kReal) ? get(ctx, n, k, t) * scale : 0.f; };
-    size_t r = 0; // record sets written so far
     for (int cp = 0; cp < npairs; ++cp) {
         for (int t = 0; t < taps; ++t) {
+            unsigned char* base = out + ((size_t)cp * taps + t) * tapStride;
             for (int half = 0; half < 2; ++half) { // main slabs: w_hi of chunk A, then of chunk B, 8 f16 per lane
                 const int c = 2 * cp + half;
                 for (int nf = 0; nf < nft; ++nf)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int rho = lane & 15, g = lane >> 4, n = chan(nf, rho);
-                        unsigned char* rec = out + r * recBytes + ((size_t)nf * 64 + lane) * 16;
+                        unsigned char* rec = base + half * mainSet + ((size_t)nf * 64 + lane) * 16;
                         for (int i = 0; i < 8; ++i) {
                             const _Float16 h = (_Float16)wval(n, c * 32 + 8 * g + i, t);
                             memcpy(rec + i * 2, &h, 2);
                         }
                     }
-                ++r;
             }
-            if (fp6) { // MX slab, kF16m6: k-group g = (chunk g>>1, term g&1), one 32-byte e2m3 block per lane
+            unsigned char* xs = base + 2 * mainSet;
+            if (fp6) { // MX slab, kF16m6: k-group g = (chunk g>>1, term g&1), one 24-byte e2m3 block + exponent per lane
                 for (int nf = 0; nf < nft; ++nf)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int rho = lane & 15, g = lane >> 4, n = chan(nf, rho);
@@ -439,8 +444,11 @@ void packTileWeightsM8(WeightGetter get, const void* ctx, int taps, int kReal, i
                         }
                         unsigned char blk[32];
                         packE2m3Block(v32, blk);
-                        for (int h16 = 0; h16 < 2; ++h16)
-                            memcpy(out + r * recBytes + (((size_t)nf * 2 + h16) * 64 + lane) * 16, blk + 16 * h16, 16);
+                        unsigned char* grp = xs + (size_t)(nf / kNfrag) * 6400;
+                        const int j4 = nf % kNfrag;
+                        memcpy(grp + (size_t)j4 * 1024 + lane * 16, blk, 16);
+                        memcpy(grp + 4096 + (size_t)j4 * 512 + lane * 8, blk + 16, 8);
+                        grp[6144 + lane * 4 + j4] = blk[24];
                     }
             } else
             for (int nf = 0; nf < nft; ++nf) // MX slab: k-group g = (chunk g>>1, term g&1), 32 fp8 per lane
@@ -448,7 +456,7 @@ void packTileWeightsM8(WeightGetter get, const void* ctx, int taps, int kReal, i
                     for (int lane = 0; lane < 64; ++lane) {
                         const int rho = lane & 15, g = lane >> 4, n = chan(nf, rho);
                         const int c = 2 * cp + (g >> 1);
-                        unsigned char* rec = out + r * recBytes + (((size_t)nf * 2 + h16) * 64 + lane) * 16;
+                        unsigned char* rec = xs + (((size_t)nf * 2 + h16) * 64 + lane) * 16;
                         for (int i = 0; i < 16; ++i) {
                             const float v = wval(n, c * 32 + 16 * h16 + i, t);
                             const _Float16 h = (_Float16)v;
@@ -457,7 +465,6 @@ void packTileWeightsM8(WeightGetter get, const void* ctx, int taps, int kReal, i
                                              : hostF32ToE4m3(std::ldexp(lo, kM8WLoShift));
                         }
                     }
-            r += 2;
         }
     }
 }

@@ -68,3 +68,22 @@ def test_more_ranks_than_gpus_is_refused():
 @pytest.mark.gpu
 def test_more_ranks_than_gpus_is_refused_on_the_gpu_box():
     test_more_ranks_than_gpus_is_refused()
+
+
+def test_cpu_baseline_times_the_product_executor(nsg):
+    """bench.py's cpu_baseline leg: the PRODUCT's restatement of the reference's EXECUTOR=random path
+    (nsg_cpu_executor, csrc/cpu_executor.cc, the reference's release flags), one core and thread pools; bounded."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline(nsg, seconds=0.3, pool_seconds=0.3, share_threads=2)
+    assert out["kind"] == "port" and out["cores"] == 1 and out["value"] > 1000 and "nsg_cpu_executor" in out["sample"]
+    assert out["gpu_share_16_threads"]["cores"] <= 2 and out["gpu_share_16_threads"]["value"] > 1000
+    assert out["all_cores"]["cores"] == out["all_cores"]["physical_cores_available"] >= 1
+    assert out["all_cores"]["value"] > 1000
+    # the release-flag build of the executor still produces the known-answer vector G1 (SURVEY.md 8c)
+    import numpy as np
+    ex = nsg.CpuExecutor("random", seed=0)
+    p, w, d = ex.compute_blocking(1)
+    assert p[0, :4].view(np.uint32).tolist() == [0x3e23a0df, 0x3f7dfd3a, 0x3d221321, 0x3f18f569]
