@@ -308,11 +308,16 @@ struct nsg_evaluator {
     DevBuf stamps;           // diagnostic builds: per-layer, per-workgroup cycle stamps
     DevBuf trunkLayers;      // persistent-trunk layer list (stem + 2 per block)
     int trunkLayerCount = 0;
-    // NSG_TRUNK_KERNEL=1: one persistent launch for all 3x3 layers (a workgroup owns its boards through every
-    // layer: no grid barrier).  Opt-in: with kF16m6 it measured +1.6-2.4 % at B = 512 on the benchmark's input (the
-    // initial position in every slot) but -1 % on distinct positions, +2.4-2.9 % at B = 256 / 384 and -3.4 % / -7 %
-    // at B = 192 / 160 (profiles/r02/g_ab_persistent_trunk_*.txt); r1: +-0 % kF16m8, -6 % kF16x3.
-    int useTrunkKernel = 0;
+    // One persistent launch for all 3x3 layers (a workgroup owns its boards through every layer: no grid barrier, no
+    // launch boundary, workgroups drift apart instead of hitting memory in lock-step).  -1 (default): taken by a
+    // kF16m6 evaluator where every tile of the batch is resident at once AND the per-layer alternatives measured
+    // slower -- on 256 CUs 144..256 boards (one-board tiles; +13 % at 160-176 where it replaces the 128 + rest
+    // two-part batch, +7 % at 192-256) and 384..512 boards (two-board tiles: +6-7 % on game positions, +3-4 % on the
+    // benchmark's replicated initial position); with more tiles than CUs the second round waits for 41 layers of the
+    // first (-35 %), 257..383 boards keep the two-part batches (profiles/r04/j_persistent_trunk_vs_per_layer_by_batch.txt).
+    // NSG_TRUNK_KERNEL=1 forces it wherever the plan allows, =0 switches it off.  (Rounds 2-3, before the loop read its
+    // weights and tiles through buffer descriptors: +1.6-2.4 % at 512, -3..-7 % at 160-192; r1: +-0 % kF16m8, -6 % kF16x3.)
+    int useTrunkKernel = -1;
 
     void* trunkOut = nullptr; // which act[] holds the trunk output of the last forward
 
@@ -769,7 +774,7 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         releaseTeamToken(ev);
     }
     const int members = (ev->tuning.nb == 0 && ev->tuning.nfrag == 0 && ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 &&
-                         !ev->useTrunkKernel) ? teamMembersFor(ev, B) : 0;
+                         ev->useTrunkKernel != 1) ? teamMembersFor(ev, B) : 0;
     if (members > 0) {
         int rc;
         {
@@ -811,7 +816,12 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         else if (2 * tiles > cus && ev->chainDelayUs != 0 && ev->prec != nsg::kFp32) chains = std::min(ev->numChains, 2);
     }
     const bool stagger = oneRound && chains > 1;
-    const bool trunkWanted = ev->useTrunkKernel == 1;
+    bool trunkWanted = ev->useTrunkKernel == 1;
+    if (ev->useTrunkKernel < 0 && ev->prec == nsg::kF16m6 && plan.nfrag == 4 && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 &&
+        ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && ev->chainMinBatch <= 0 && ev->chainDelayUs == 0) {
+        const long t = (B + plan.nb - 1) / plan.nb; // tiles = workgroups of the persistent launch
+        trunkWanted = t <= cus && (plan.nb == 1 ? t * 16 >= (long)cus * 9 : t * 4 >= (long)cus * 3);
+    }
     const bool trunkKernel = trunkWanted && !ev->W->outsideM8Window && nsg::canRunTrunk(ev->F, plan);
     if (trunkKernel) chains = 1;
     const int per = ((B + chains - 1) / chains + 1) / 2 * 2; // boards per chain, whole 2-board tiles
@@ -974,7 +984,7 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
         NSG_HIP(hipMemcpy(ev->trunkLayers.p, host.data(), host.size(), hipMemcpyHostToDevice));
         ev->trunkLayerCount = nl;
         const char* env = getenv("NSG_TRUNK_KERNEL");
-        ev->useTrunkKernel = (env && env[0] == '1') ? 1 : 0;
+        ev->useTrunkKernel = !env ? -1 : (env[0] == '1' ? 1 : 0);
     }
     // team trunk layer list: the kF16x3 copy of the trunk (an MX evaluator keeps one for batches without an MX plan;
     // a kF16x3 evaluator's own records), same buffer rotation

@@ -765,7 +765,13 @@ def test_two_part_batches(nsg, oracle, monkeypatch, mx):
     net = oracle.net(blob)
     for n in sizes:
         p, v, d = ev.compute_blocking(bb[:n])
-        assert ev.last_plan()["chains"] == 2 and ev.last_plan()["trunk_precision"] == mx, (n, ev.last_plan())
+        # (round 4: where every one-board tile of the batch is resident at once, 9/16 CUs .. CUs boards, an f16m6
+        # evaluator runs the persistent trunk launch instead -- one chain; the same bits as its per-layer kernels;
+        # likewise 3/4 CUs .. CUs two-board tiles)
+        t2 = (n + 1) // 2  # two-board tiles
+        persistent = mx == "f16m6" and (9 * cus <= 16 * n <= 16 * cus or
+                                        (ev.last_plan()["boards_per_group"] == 2 and 3 * cus <= 4 * t2 and t2 <= cus))
+        assert ev.last_plan()["chains"] == (1 if persistent else 2) and ev.last_plan()["trunk_precision"] == mx, (n, ev.last_plan())
         p1, v1, d1 = one.compute_blocking(bb[:n])
         assert one.last_plan()["chains"] == (1 if n <= 2 * cus else 2)  # (more tiles than CUs: two half-batch chains)
         p3, v3, d3 = x3.compute_blocking(bb[:n])
