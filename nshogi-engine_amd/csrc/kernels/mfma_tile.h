@@ -109,7 +109,9 @@ __device__ __forceinline__ int entryOfRow(int m) {
 // stores per thread for the eight resident buffers of a K-split tile, 2.8k of its 9.7k prologue cycles)
 // is 2-3x the work needed.  Lane l owns halo entry l (+64, ...) and walks the planes: one address
 // computation per entry, then stores at a constant stride.
-template <class G>
+// SHIFT (kF16m6 conv images): plane 7 of every chunk buffer -- the second 16-byte piece of the lo block, [code dwords 4-5,
+// exponent, exponent] -- lives 8 bytes further on (tileBody, kShiftLo): its halo pieces are cleared there.
+template <class G, bool SHIFT = false>
 __device__ __forceinline__ void zeroHalo(unsigned char* smem, int tid) {
     static_assert(G::kBoards, "board images only");
     constexpr int kBoardsN = (G::kEntries - 24) / 110;
@@ -137,7 +139,13 @@ __device__ __forceinline__ void zeroHalo(unsigned char* smem, int tid) {
         for (int pl = 0; pl < (kPlanes + kWavesN - 1) / kWavesN; ++pl) {
             int plane = pl * kWavesN + wave;
             plane = plane < kPlanes ? plane : kPlanes - 1;
-            *reinterpret_cast<u32x4*>(smem + e * 16 + (size_t)plane * G::kPlane) = u32x4{0u, 0u, 0u, 0u};
+            if constexpr (SHIFT) {
+                unsigned char* z = smem + e * 16 + (size_t)plane * G::kPlane + ((plane & 7) == 7 ? 8 : 0);
+                *reinterpret_cast<u32x2*>(z) = u32x2{0u, 0u};
+                *reinterpret_cast<u32x2*>(z + 8) = u32x2{0u, 0u};
+            } else {
+                *reinterpret_cast<u32x4*>(smem + e * 16 + (size_t)plane * G::kPlane) = u32x4{0u, 0u, 0u, 0u};
+            }
         }
     }
 }
@@ -557,6 +565,25 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     // per-lane tables, the weight pointers and the first weight records are set up -- the prologue of these
     // small-batch kernels is a third of their run time, and it used to spend 5k cycles before the last tile
     // load was even issued (profiles/r01/h_stamps_f16m8_b64_ksplit4.txt).
+    // kF16m6 conv images: the second piece of a row's lo block ([code dwords 4-5, exponent, exponent]; plane 7 of a
+    // chunk buffer) is stored 8 bytes further on than its entry's slot -- pieces still tile the plane, one slot later by
+    // half -- so that the 8-byte reads of the hi and the lo block's dwords 4-5 (lane groups g and g + 1 of one LDS
+    // half-wave, planes 5 and 7: the same banks otherwise) fall on disjoint banks.  Staged pieces are written as two
+    // 8-byte stores (8-byte aligned everywhere; the cost of one 16-byte store).  See kSplitRead in the main loop.
+    // OPT-IN (make ab ABFLAGS=-DNSG_MX_SPLIT_READ), measured no faster: see kSplitRead in the main loop.
+#ifdef NSG_MX_SPLIT_READ
+    constexpr bool kShiftLo = (PREC == kF16m6) && MODE == kConv;
+#else
+    constexpr bool kShiftLo = false;
+#endif
+    auto stageStore = [](unsigned char* p_, const u32x4& v_) {
+        if constexpr (kShiftLo) {
+            *reinterpret_cast<u32x2*>(p_) = u32x2{v_.x, v_.y};
+            *reinterpret_cast<u32x2*>(p_ + 8) = u32x2{v_.z, v_.w};
+        } else {
+            *reinterpret_cast<u32x4*>(p_) = v_;
+        }
+    };
     constexpr bool kResident = isMx(PREC) && KS > 1;
     constexpr int kResChunks = 8;
     u32x4 stAll[kResident ? kResChunks : 1][G::kItems];
@@ -580,7 +607,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         // every masked store a 64-way same-address conflict that stalled the whole LDS): the store
         // stays unconditional, so st[] stays in registers
         // (bit select, not ?: -- the compiler turned the conditional into a far out-of-line block per item)
-        const int okOff = c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16, okMask = -(int)itemOk[k];
+        const int okOff = c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16 + ((kShiftLo && c == 7) ? 8 : 0), okMask = -(int)itemOk[k];
         dstOff[k] = (okOff & okMask) | ((G::kLds + lane * 16) & ~okMask);
     }
 
@@ -631,8 +658,7 @@ _Pragma("unroll") \
     }
 #define NSG_STAGE_WRITE(BUF)                                                             \
     _Pragma("unroll") for (int k = 0; k < G::kItems; ++k) {                              \
-        *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? (BUF) * G::kBuf : 0) + dstOff[k]) = \
-            st[k];                                                                       \
+        stageStore(smem + (itemOk[k] ? (BUF) * G::kBuf : 0) + dstOff[k], st[k]);         \
     }
 
     f32x4 acc[kMFw][NFRAG];
@@ -755,39 +781,43 @@ _Pragma("unroll") \
         for (int k = 0; k < G::kItems; ++k) st1[k] = tileLoad(k, 1);
         NSG_STAMP(4);
         if constexpr (kPerm) { NSG_COMPUTE_ABASE }
-        if (zeroLds) zeroHalo<G>(smem, tid);
+        if (zeroLds) zeroHalo<G, kShiftLo>(smem, tid);
         __syncthreads(); // zero fill done before staging writes
         NSG_STAMP(5);
         NSG_STAGE_WRITE(0)
 #pragma unroll
         for (int k = 0; k < G::kItems; ++k)
-            *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? G::kBuf : 0) + dstOff[k]) = st1[k];
+            stageStore(smem + (itemOk[k] ? G::kBuf : 0) + dstOff[k], st1[k]);
         __syncthreads();
         } else {
             // every chunk of the board (at most eight) was requested at the top of the kernel
             constexpr int kChunks = kResChunks;
-            if (zeroLds) zeroHalo<G>(smem, tid);
+            if (zeroLds) zeroHalo<G, kShiftLo>(smem, tid);
             __syncthreads();
             NSG_STAMP(5); // image cleared; what follows waits for the tile loads
 #pragma unroll
             for (int c = 0; c < kChunks; ++c)
 #pragma unroll
                 for (int k = 0; k < G::kItems; ++k)
-                    if (__builtin_expect(c < nkc, 1)) *reinterpret_cast<u32x4*>(smem + (itemOk[k] ? c * G::kBuf : 0) + dstOff[k]) = stAll[c][k];
+                    if (__builtin_expect(c < nkc, 1)) stageStore(smem + (itemOk[k] ? c * G::kBuf : 0) + dstOff[k], stAll[c][k]);
             __syncthreads();
         }
         NSG_STAMP(1);
 
-        // Opt-in (make ab ABFLAGS=-DNSG_MX_SPLIT_READ), MEASURED SLOWER: -3 % at 512 boards, -4 % at 1024, +-0.5 % at 32-256
-        // (profiles/r04/d_ab_split_mx_operand_read_and_spread_requests.txt).  It removes every copy in front of the MX
-        // steps (88 v_accvgpr_write + 80 s_nop per chunk pair, see below) and the SS = 2 / 4 kernels' spills, but its
-        // 8- and 4-byte reads walk the image at its 16-byte entry stride: 4-way bank conflicts, where the 16-byte reads
-        // have none or two -- the LDS, not the issue port, is what the two-board tiles' MX slabs wait for.
-#ifdef NSG_MX_SPLIT_READ
-        constexpr bool kSplitRead = kM6 && OS::kX > 0;
-#else
-        constexpr bool kSplitRead = false;
-#endif
+        // The MX row operand of the e2m3 form is six code dwords + the block's exponent (which must sit in an arch
+        // VGPR).  Read as two 16-byte pieces, the second is half codes, half exponent: the register allocator, out of
+        // arch VGPRs, loads the codes elsewhere and COPIES them next to the first half -- 138 moves + 87 s_nop per chunk
+        // pair in front of the MX steps' first MFMAs.  kSplitRead (-DNSG_MX_SPLIT_READ) reads 16 bytes (dwords 0-3) + 8
+        // bytes (dwords 4-5), both wholly inside the operand, + 4 bytes (the exponent's second copy, at byte 12 of the
+        // piece: a read of byte 8 would be fused with the 8-byte read into a 12-byte one and copied again), with the lo
+        // block's second piece 8 bytes off its slot (kShiftLo) so that the narrow reads of lane groups g, g + 1 use
+        // disjoint banks.  The loop then has no move, no s_nop and no accumulator-file copy left -- and is NOT faster:
+        // 512 boards -1.3 %, 32-64 boards -1.6...-3 %, the rest +-0.5 % (profiles/r04/m_ab_shifted_plane_split_mx_read.txt;
+        // without the shift -3...-4 %, d_ab_*).  The copies issue in the shadow of the step's MFMAs; a third LDS
+        // instruction per MX step does not.  What the loop is short of is LDS issue, not vector issue.
+        constexpr bool kSplitRead = kShiftLo && OS::kX > 0;
+        // (without the split read, plane 7's shift still applies: its piece is read at + 8)
+        const int offB = offp8 + G::kPlane + 8 * (g & 1);
         u32x4 aw[kWin][kSplitRead ? 1 : 2];
         [[maybe_unused]] u32x2 aw45[kSplitRead ? kWin : 1];
         [[maybe_unused]] uint32_t awS[kSplitRead ? kWin : 1];
@@ -800,9 +830,12 @@ _Pragma("unroll") \
             if (Q::isX(s_)) {                                                                     \
                 const unsigned char* ap_ = b_ + abase[f_] + offp8 + tapOff(Q::tap(s_));           \
                 aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(ap_);                        \
+                [[maybe_unused]] const unsigned char* ap2_ = b_ + abase[f_] + offB + tapOff(Q::tap(s_)); \
                 if constexpr (kSplitRead) {                                                       \
-                    aw45[(QQ) % kWin] = *reinterpret_cast<const u32x2*>(ap_ + G::kPlane);         \
-                    awS[(QQ) % kWin] = *reinterpret_cast<const uint32_t*>(ap_ + G::kPlane + 12);   \
+                    aw45[(QQ) % kWin] = *reinterpret_cast<const u32x2*>(ap2_);                    \
+                    awS[(QQ) % kWin] = *reinterpret_cast<const uint32_t*>(ap2_ + 12);             \
+                } else if constexpr (kShiftLo) {                                                  \
+                    aw[(QQ) % kWin][kSplitRead ? 0 : 1] = *reinterpret_cast<const u32x4*>(ap2_);  \
                 } else {                                                                          \
                     aw[(QQ) % kWin][kSplitRead ? 0 : 1] = *reinterpret_cast<const u32x4*>(ap_ + G::kPlane); \
                 }                                                                                 \
