@@ -277,6 +277,13 @@ int nsg_get_stats(nsg_evaluator* ev, uint64_t* batches, uint64_t* positions);
  * -1 another process holds the device's token; *members_last: workgroups per board of the most recent team
  * launch; *fallbacks: launches that gave up and were re-run. */
 int nsg_get_team_stats(nsg_evaluator* ev, int* enabled, int* members_last, uint64_t* fallbacks);
+/* How the most recent forward pass launched its trunk: 0 = per-layer kernels (or the persistent launch whose workgroups
+ * own whole boards: no hand-off), 1 = the team trunk, 2 = the cooperative trunk -- the two-way K split of 65 ... CUs/2
+ * boards of a 256-channel F16M6 net as ONE launch whose two workgroups per board hand their channel halves to each
+ * other (same residency rule, device token, give-up and re-run as the team trunk; NSG_COOP_TRUNK=0 switches it off).
+ * *coop_enabled: 1 in use, 0 off (not applicable, switched off, or after a fallback), -1 another process holds the
+ * device's token. */
+int nsg_get_last_launch_kind(nsg_evaluator* ev, int* kind, int* coop_enabled);
 
 /* Launch plan of the most recent forward pass (tests and tuning): boards per
  * workgroup, 16-channel fragments per wave, waves per workgroup, and the number

@@ -104,6 +104,7 @@ def load_library():
     ip = ctypes.POINTER(ctypes.c_int)
     lib.nsg_get_last_plan.argtypes = [vp, ip, ip, ip, ip]
     lib.nsg_get_team_stats.argtypes = [vp, ip, ip, ctypes.POINTER(ctypes.c_uint64)]
+    lib.nsg_get_last_launch_kind.argtypes = [vp, ip, ip]
     lib.nsg_get_last_trunk_precision.argtypes = [vp, ip]
     lib.nsg_get_last_split.argtypes = [vp, ip, ip]
     lib.nsg_get_last_slab_split.argtypes = [vp, ip]
@@ -317,6 +318,12 @@ class Evaluator:
         en, mem, fb = ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64()
         _check(self._lib.nsg_get_team_stats(self._h, ctypes.byref(en), ctypes.byref(mem), ctypes.byref(fb)))
         return {"enabled": en.value, "members_last": mem.value, "fallbacks": fb.value}
+
+    def last_launch_kind(self):
+        """nsg_get_last_launch_kind: ("per_layer" | "team" | "coop", cooperative trunk in use 1 / 0 / -1)."""
+        k, c = ctypes.c_int(), ctypes.c_int()
+        _check(self._lib.nsg_get_last_launch_kind(self._h, ctypes.byref(k), ctypes.byref(c)))
+        return {0: "per_layer", 1: "team", 2: "coop"}.get(k.value, k.value), c.value
 
     def last_plan(self):
         """Launch plan of the most recent forward pass (nsg_get_last_plan)."""

@@ -126,6 +126,17 @@ bool canRunTrunk(int cout, const ConvPlan& plan);
 hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
                        const ConvPlan& plan, hipStream_t stream);
 
+// Cooperative trunk (mfma_tile.h, coopTrunkKernel): every 3x3 layer of a mid batch whose boards are shared by several
+// workgroups (K-split plans) in ONE launch; workgroups of a board hand their output slices to each other through
+// agent-scope stores / loads and one flag per (board, member) in `flags` (batch x members unsigned, zeroed before the
+// launch).  kF16m6, 256 channels, the two-way K split (65 ... CUs/2 boards).  All batch x members workgroups must be
+// resident at once.  `status`: host-mapped int raised when a bounded spin runs out.
+bool canRunCoopTrunk(int cout, int stemKdim, int prec, const ConvPlan& plan);
+int coopMembers(int cout, const ConvPlan& plan); // workgroups per board
+// (faultBoard >= 0: test hook -- that board's second member leaves at once, so its first waits in vain)
+hipError_t launchCoopTrunk(const void* devLayers, int nLayers, int batch, int cout, int prec, const ConvPlan& plan,
+                           unsigned* flags, int* status, hipStream_t stream, int faultBoard = -1);
+
 // Team trunk (team_trunk.hip): every 3x3 layer of up to sixteen boards in ONE persistent launch, a board per team of
 // 16 / 32 / 48 / 96 workgroups (12 / 24 / 36 / 72 for 192 trunk channels) that hand activations to each other through
 // agent-scope stores / loads; the payload is its own flag (TeamHandoff).  kF16x3 arithmetic, records and activation

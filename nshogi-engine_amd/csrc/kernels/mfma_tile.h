@@ -474,8 +474,12 @@ struct StepSeq {
 // per CU: 2.4 MB = 17 us per layer, more than the MFMAs of a one-board tile take); the K split streams
 // it once.  All 2*KS*... chunk tiles of the board are resident in LDS at once (eight image buffers for
 // 256 channels), so the loop has no staging and no barriers.
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1, int SS = 1, int PART = 0>
+// COOP (coopTrunkKernel): the workgroup's input rows were written by OTHER workgroups of the same launch -- every load
+// of activations (input tiles, residual) is an agent-scope (sc1) buffer load that never hits this CU's L1, every output
+// store a write-through (sc1) buffer store.
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1, int SS = 1, int PART = 0, bool COOP = false>
 __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
+    static_assert(!COOP || (isMx(PREC) && MODE == kConv && NFRAG == 4), "cooperative trunk: MX conv tiles");
     static_assert(SS == 1 || (isMx(PREC) && MODE == kConv && SIZE == 2 && MS == 1 && KS == 1 && NWAVES % SS == 0 && PART < SS),
                   "slab split: two-board MX conv tiles");
     using G = Geom<MODE, SIZE, NWAVES, (isMx(PREC) ? (KS > 1 ? 8 : 4) : 2)>;
@@ -557,7 +561,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
         for (int k = 0; k < G::kItems; ++k) srcRel[k] = (int)(srcOff[k] - row0 * (size_t)A.kdim * ES);
     }
     auto tileLoad = [&](int k, int chunk) -> u32x4 { // item k of channel chunk `chunk` (wave-uniform)
-        if constexpr (kTileBuf) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, srcRel[k], chunk * 128, 0));
+        if constexpr (kTileBuf) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, srcRel[k], chunk * 128, COOP ? 16 /* sc1 */ : 0));
         else return *reinterpret_cast<const u32x4*>(A.x + srcOff[k] + (size_t)chunk * 128);
     };
     u32x4 st[G::kItems];
@@ -1411,6 +1415,19 @@ _Pragma("unroll") \
         const size_t tileOff = (row0 + (kPerm ? (size_t)0 : (size_t)fBaseE * 16)) * rowBytes + sliceOff; // (edge-packed: the table holds offsets inside the tile)
         const unsigned char* resBase = A.res + tileOff;
         unsigned char* yBase = A.y + tileOff;
+        [[maybe_unused]] __amdgpu_buffer_rsrc_t resRs, yRs;
+        if constexpr (COOP) {
+            resRs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(resBase), 0, 0x7fffffff, 0x00027000);
+            yRs = __builtin_amdgcn_make_buffer_rsrc(yBase, 0, 0x7fffffff, 0x00027000);
+        }
+        auto resLoad = [&](size_t off_) -> u32x4 {
+            if constexpr (COOP) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(resRs, (int)off_, 0, 16));
+            else return *reinterpret_cast<const u32x4*>(resBase + off_);
+        };
+        auto outStore = [&](size_t off_, const u32x4& v_) {
+            if constexpr (COOP) __builtin_amdgcn_raw_buffer_store_b128(v_, yRs, (int)off_, 0, 16);
+            else *reinterpret_cast<u32x4*>(yBase + off_) = v_;
+        };
         // edge-packed rows: per-lane offsets of the four rows (it = 0..3) this lane moves for fragment f
         [[maybe_unused]] const unsigned permLane = (unsigned)lpc * 16u;
         constexpr int kFBasePerm = PART * kMFe; // (edge-packed tiles have no K split: the first fragment is static)
@@ -1444,7 +1461,7 @@ _Pragma("unroll") \
                 for (int it = 0; it < kIPF; ++it) {
                     rpre[f][it] = u32x4{0u, 0u, 0u, 0u};
                     if (__builtin_expect(rowOk(f, it, ro), 1))
-                        rpre[f][it] = *reinterpret_cast<const u32x4*>(resBase + rowByte(f, it, ro));
+                        rpre[f][it] = resLoad(rowByte(f, it, ro));
                 }
             }
         }
@@ -1484,7 +1501,7 @@ _Pragma("unroll") \
                         t = rpre[f < kPreFrags ? f : 0][it];
                     } else {
                         if (__builtin_expect(rowOk(f, it, ro), 1))
-                            t = *reinterpret_cast<const u32x4*>(resBase + rowByte(f, it, ro));
+                            t = resLoad(rowByte(f, it, ro));
                     }
                     *reinterpret_cast<u32x4*>(ebuf + (f % kRegions) * kFragBytes + r * kRowS + lpc * 16) = t;
                 }
@@ -1700,7 +1717,7 @@ _Pragma("unroll") \
 #else
                     if (__builtin_expect(rowOk(f, it, ro), 1))
 #endif
-                        *reinterpret_cast<u32x4*>(yBase + rowByte(f, it, ro)) = tt[it];
+                        outStore(rowByte(f, it, ro), tt[it]);
                 }
             }
         }
@@ -1814,6 +1831,68 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
     }
 }
 
+// Cooperative trunk: every 3x3 layer of a batch whose boards are shared by SEVERAL workgroups (the K-split plans of the
+// mid batches: gridDim.y workgroups per board, each a 64- or 128-channel slice) in ONE launch.  A per-layer kernel ends
+// when its slowest workgroup does, 41 times per forward; here a workgroup waits only for the other workgroups OF ITS
+// BOARD: member m of board b publishes flag[b][m] = l + 1 behind its layer-l stores and polls its neighbours' flags
+// before layer l + 1.  The hand-off is MI355X_MICROARCH's measured form: every store of the payload sc1 (write-through),
+// every storing wave waits for its stores (vmcnt(0)), a workgroup barrier, ONE lane stores the flag (sc1); the consumer
+// polls with sc1 loads, a workgroup barrier, then reads the payload with sc1 loads only (tileBody, COOP).  The flag
+// of layer l also orders the write-after-read hazards of the three rotating activation buffers: a member can reach the
+// epilogue of layer l + 2 (which overwrites what layer l + 1 read) only behind every neighbour's flag l + 2.
+// All gridDim.x * gridDim.y workgroups must be resident (the host checks the grid against the CU count and keeps one
+// such launch per device); every spin is bounded (~1 s): a member that gives up raises the host-mapped `status` and
+// the launch unwinds; the host re-runs the batch on the per-layer kernels (nsg_capi.hip, teamRecover).
+template <int PREC, int NFRAG, int NWAVES, int KS>
+__global__ __launch_bounds__(NWAVES * 64, 1) void coopTrunkKernel(const Args* __restrict__ layers, int nLayers,
+                                                                  unsigned* flags, int* status, int faultBoard) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = Geom<kConv, 1, NWAVES, 8>;
+    if ((int)blockIdx.x == faultBoard && blockIdx.y == 1) return; // (test hook: this member never publishes)
+    int* gaveUp = reinterpret_cast<int*>(smem + G::kLdsAlloc); // one int behind everything tileBody uses
+    const int members = (int)gridDim.y, me = (int)blockIdx.y;
+    unsigned* mine = flags + (size_t)blockIdx.x * members;
+    if (threadIdx.x == 0) *gaveUp = 0;
+    for (int l = 0; l < nLayers; ++l) {
+        if (l > 0) {
+            if ((int)threadIdx.x < members && (int)threadIdx.x != me) { // one polling lane per neighbour (wave 0)
+                int spins = 0;
+                while (__hip_atomic_load(mine + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l) {
+                    if ((++spins & 255) == 0 &&
+                        (spins > (1 << 21) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                        __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        *gaveUp = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __syncthreads(); // the other waves load behind the polling wave's match
+            if (*gaveUp) return;
+        }
+        const Args A = layers[l];
+        if (A.res) tileBody<PREC, kConv, 1, NFRAG, NWAVES, 1, 1, KS, 1, 0, true>(A, smem, true);
+        else tileBody<PREC, kConv, 1, NFRAG, NWAVES, 0, 1, KS, 1, 0, true>(A, smem, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its write-through stores have left
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(mine + me, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int PREC, int NFRAG, int NWAVES, int KS>
+hipError_t launchCoopOne(const Args* layers, int nLayers, int boards, int cout, unsigned* flags, int* status, hipStream_t stream,
+                         int faultBoard) {
+    using G = Geom<kConv, 1, NWAVES, 8>;
+    constexpr int kChanGroups = NWAVES / KS;
+    const int gy = cout / (kChanGroups * NFRAG * 16);
+    if (gy < 1 || gy * kChanGroups * NFRAG * 16 != cout || gy > 64) return hipErrorInvalidValue;
+    auto k = coopTrunkKernel<PREC, NFRAG, NWAVES, KS>;
+    const hipError_t err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc + 16);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k, dim3(boards, gy), dim3(G::kThreads), G::kLdsAlloc + 16, stream, layers, nLayers, flags, status, faultBoard);
+    return hipGetLastError();
+}
+
 #ifdef NSG_EXP_RUNTIME
 inline int expFlags() { const char* e = getenv("NSG_EXP_FLAGS"); return e ? atoi(e) << 2 : 0; }
 #else
@@ -1921,6 +2000,8 @@ hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStrea
 hipError_t launchTrunkF16m8(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchConvF16m6(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkF16m6(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
+hipError_t launchCoopTrunkF16m6(const Args* layers, int n, int batch, int cout, const ConvPlan& p, unsigned* flags, int* status,
+                                hipStream_t s, int faultBoard);
 hipError_t launchTrunkFp32(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkFp16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkBf16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);

@@ -62,5 +62,13 @@ hipError_t launchTrunkF16m6(const Args* layers, int n, int batch, const ConvPlan
     return hipErrorInvalidValue;
 }
 
+hipError_t launchCoopTrunkF16m6(const Args* layers, int n, int batch, int cout, const ConvPlan& p, unsigned* flags, int* status,
+                                hipStream_t s, int faultBoard) {
+    // the two-way K split of the mid batches: two workgroups per board (128 channels each) on 256 channels
+    if (p.nb == 1 && p.nfrag == 4 && p.nwaves == 4 && p.ksplit == 2 && p.msplit == 1 && p.sslab == 1)
+        return launchCoopOne<kF16m6, 4, 4, 2>(layers, n, batch, cout, flags, status, s, faultBoard);
+    return hipErrorInvalidValue;
+}
+
 } // namespace tile
 } // namespace nsg

@@ -153,6 +153,20 @@ hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
     return hipErrorInvalidValue;
 }
 
+bool canRunCoopTrunk(int cout, int stemKdim, int prec, const ConvPlan& plan) {
+    // every layer, the stem included, must run the same kernel: two K halves of whole chunk pairs
+    return prec == kF16m6 && cout == 256 && stemKdim % 128 == 0 && stemKdim <= 256 && plan.nb == 1 && plan.nfrag == kNfrag &&
+           plan.nwaves == 4 && plan.ksplit == 2 && plan.msplit == 1 && plan.sslab == 1;
+}
+
+int coopMembers(int cout, const ConvPlan& plan) { return cout / ((plan.nwaves / plan.ksplit) * plan.nfrag * 16); }
+
+hipError_t launchCoopTrunk(const void* devLayers, int nLayers, int batch, int cout, int prec, const ConvPlan& plan,
+                           unsigned* flags, int* status, hipStream_t stream, int faultBoard) {
+    if (batch <= 0 || nLayers <= 0 || !flags || !status || prec != kF16m6) return hipErrorInvalidValue;
+    return tile::launchCoopTrunkF16m6((const tile::Args*)devLayers, nLayers, batch, cout, plan, flags, status, stream, faultBoard);
+}
+
 hipError_t launchHeads(const void* x, const void* wfrag, const float* bias,
                        float* policy, void* vfeat, int batch, int channels,
                        int coutPadded, int valueChannels, int vfeatStride,

@@ -336,6 +336,12 @@ struct nsg_evaluator {
     uint64_t teamFallbacks = 0; // team launches that gave up and were re-run on the per-layer kernels (nsg_get_team_stats)
     int teamLockedOut = 0;      // another PROCESS holds this device's team token (teamDeviceLock): per-layer kernels only
     bool teamLockHeld = false;  // this evaluator holds a reference on the process's lock of the device
+    // Cooperative trunk (mfma_tile.h, coopTrunkKernel): the two-way K split of 65 ... CUs/2 boards as ONE launch whose
+    // two workgroups per board hand their halves to each other.  NSG_COOP_TRUNK=0 switches it off.  Shares the team
+    // trunk's device token (both need every workgroup of their grid resident), status word and recovery.
+    DevBuf coopFlags;           // [batchMax][members] unsigned, zeroed before every launch
+    int coopEnabled = 1;
+    int lastPersistent = 0;     // what the most recent forward ran: 0 per-layer / persistent-without-hand-off, 1 team trunk, 2 cooperative trunk
     int teamFaultLaunches = 0;  // NSG_TEAM_FAULT_LAUNCHES (test hook): this many team launches are made ONE WORKGROUP SHORT,
                                 // so that the team waits in vain, gives up and the recovery path runs
     // What the most recent compute call queued behind its forward: should the team launch of that forward give up
@@ -591,6 +597,46 @@ int enqueueTeam(nsg_evaluator* ev, int B, int members, hipStream_t s, hipEvent_t
     return NSG_OK;
 }
 
+// The value / policy heads behind a trunk whose output is `x` (the tail of every forward).
+int enqueueHeads(nsg_evaluator* ev, void* x, int B, int hprec, hipStream_t s) {
+    Range headsRange("nsg.heads");
+    NSG_HIP(nsg::launchHeads(x, ev->W->heads.w.p, (const float*)ev->W->heads.bias.p, (float*)ev->policy.p, ev->vfeat.p, B,
+                             ev->F, ev->headsCout, ev->vc, ev->fc1K, ev->W->heads.accScale, hprec, s));
+    const size_t partStride = (size_t)ev->batchMax * ev->vh;
+    NSG_HIP(nsg::launchDense(ev->vfeat.p, ev->W->fc1.w.p, (const float*)ev->W->fc1.bias.p, (float*)ev->hidden.p, B,
+                             ev->fc1K, ev->vh, partStride, ev->W->fc1.accScale, hprec, s));
+    NSG_HIP(nsg::launchValueOut((const float*)ev->hidden.p, (const float*)ev->W->fc1.bias.p, nsg::denseSplits(ev->fc1K, hprec),
+                                partStride, (const float*)ev->W->fc2W.p, (const float*)ev->W->fc2B.p, (float*)ev->value.p,
+                                (float*)ev->draw.p, B, ev->vh, s));
+    return NSG_OK;
+}
+
+// The whole forward of a mid batch with the cooperative trunk (under the device's token: enqueueForward).
+int enqueueCoop(nsg_evaluator* ev, int B, const nsg::ConvPlan& plan, hipStream_t s, hipEvent_t trunkBegin, hipEvent_t trunkEnd) {
+    const int prec = ev->prec;
+    ev->lastTrunkPrec = prec;
+    {
+        Range r("nsg.planes");
+        NSG_HIP(nsg::launchExtractBitsAct(ev->planes.p, (const uint64_t*)ev->input.p, B, ev->numChannels, ev->cpad, prec, s));
+    }
+    {
+        Range r("nsg.trunk");
+        const int members = nsg::coopMembers(ev->F, plan);
+        NSG_HIP(hipMemsetAsync(ev->coopFlags.p, 0, (size_t)B * members * sizeof(unsigned), s));
+        if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
+        // (test hook NSG_TEAM_FAULT_LAUNCHES: the last board's second member leaves at once and never publishes)
+        const int faultBoard = ev->teamFaultLaunches > 0 ? B - 1 : -1;
+        if (faultBoard >= 0) --ev->teamFaultLaunches;
+        NSG_HIP(nsg::launchCoopTrunk(ev->trunkLayers.p, ev->trunkLayerCount, B, ev->F, prec, plan,
+                                     (unsigned*)ev->coopFlags.p, ev->teamStatusDev, s, faultBoard));
+        NSG_HIP(hipEventRecord(ev->teamDone, s));
+        if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
+    }
+    void* x = (ev->blocks % 2 == 1) ? ev->act[2].p : ev->act[0].p; // the buffer rotation of the layer list
+    ev->trunkOut = x;
+    return enqueueHeads(ev, x, B, nsg::headPrecision(prec), s);
+}
+
 // One chain = the whole forward for boards [off, off + count) on stream `s`.
 int enqueueChain(nsg_evaluator* ev, int off, int count, const nsg::ConvPlan& plan, hipStream_t s,
                  bool stampsOk, hipEvent_t trunkBegin = nullptr, hipEvent_t trunkEnd = nullptr) {
@@ -765,11 +811,13 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     // (kernels/team_trunk.hip), when no tuning override asks for a particular per-layer plan and no other evaluator
     // has a team launch in flight on this device.
     ev->teamLast = false;
+    ev->lastPersistent = 0;
     // (a give-up word still raised here belongs to a forward nobody waited for: its batch is gone, the team path is not
     // taken again)
     if (ev->teamStatusHost && *ev->teamStatusHost != 0) {
         *ev->teamStatusHost = 0;
         ev->teamEnabled = 0;
+        ev->coopEnabled = 0;
         ++ev->teamFallbacks;
         releaseTeamToken(ev);
     }
@@ -784,9 +832,35 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         }
         if (rc) return rc;
         ev->teamLast = true;
+        ev->lastPersistent = 1;
         plan = nsg::ConvPlan{};
         plan.nb = 1; plan.nfrag = 1; plan.nwaves = 8; plan.ksplit = 8; // 16 weight fragments x 2 or 6 row groups per board, K over 8 waves
         plan.msplit = members / (ev->F / 16); // row groups
+        ev->lastPlan = plan;
+        ev->lastChains = 1;
+        if (prof) {
+            NSG_HIP(hipEventRecord(e[3], s));
+            ev->evUsed += 4;
+            ev->pendingTrunkLaunchesPerFwd = 1;
+        }
+        return NSG_OK;
+    }
+
+    // Mid batches on the two-way K split: the cooperative trunk, when every workgroup of its grid is resident at once
+    // (same token as the team trunk: one such launch per device at a time)
+    if (ev->coopEnabled && ev->teamStatusDev && ev->coopFlags.p && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 &&
+        ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && ev->useTrunkKernel != 1 && mx && ev->chainMinBatch <= 0 &&
+        ev->chainDelayUs == 0 && nsg::canRunCoopTrunk(ev->F, ev->cpad, ev->prec, plan) &&
+        (long)B * nsg::coopMembers(ev->F, plan) <= ev->prop.multiProcessorCount) {
+        int rc;
+        {
+            TeamTokenGuard token(ev);
+            if (!token.held) return fail(NSG_E_HIP, "cooperative trunk: hipStreamWaitEvent on the device's other persistent launch failed");
+            rc = enqueueCoop(ev, B, plan, s, prof ? e[1] : nullptr, prof ? e[2] : nullptr);
+        }
+        if (rc) return rc;
+        ev->teamLast = true;
+        ev->lastPersistent = 2;
         ev->lastPlan = plan;
         ev->lastChains = 1;
         if (prof) {
@@ -986,6 +1060,22 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
         const char* env = getenv("NSG_TRUNK_KERNEL");
         ev->useTrunkKernel = !env ? -1 : (env[0] == '1' ? 1 : 0);
     }
+    // what the persistent launches with hand-offs share: the event behind the most recent one, the host-mapped give-up word
+    if (!ev->teamDone) NSG_HIP(hipEventCreateWithFlags(&ev->teamDone, hipEventDisableTiming));
+    if (!ev->teamStatusHost) {
+        NSG_HIP(hipHostMalloc((void**)&ev->teamStatusHost, 64, hipHostMallocMapped));
+        *ev->teamStatusHost = 0;
+        NSG_HIP(hipHostGetDevicePointer((void**)&ev->teamStatusDev, ev->teamStatusHost, 0));
+    }
+    {   // cooperative trunk (mid batches): flags of (board, member)
+        const char* env = getenv("NSG_COOP_TRUNK");
+        ev->coopEnabled = (env && env[0] == '0') ? 0 : 1;
+        if (prec == nsg::kF16m6 && N.F == 256 && ev->coopEnabled) {
+            if ((rc = ev->coopFlags.alloc((size_t)ev->batchMax * 8 * sizeof(unsigned), true))) return rc;
+        } else {
+            ev->coopEnabled = 0;
+        }
+    }
     // team trunk layer list: the kF16x3 copy of the trunk (an MX evaluator keeps one for batches without an MX plan;
     // a kF16x3 evaluator's own records), same buffer rotation
     ev->teamLayerCount = 0;
@@ -1016,20 +1106,17 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
         NSG_HIP(hipMemset(ev->teamSets.p, 0xff, setsBytes));
         ev->teamSet = 0;
         ev->teamDirty[0] = ev->teamDirty[1] = 0;
-        if (!ev->teamDone) NSG_HIP(hipEventCreateWithFlags(&ev->teamDone, hipEventDisableTiming));
-        if (!ev->teamStatusHost) {
-            NSG_HIP(hipHostMalloc((void**)&ev->teamStatusHost, 64, hipHostMallocMapped));
-            *ev->teamStatusHost = 0;
-            NSG_HIP(hipHostGetDevicePointer((void**)&ev->teamStatusDev, ev->teamStatusHost, 0));
-        }
         ev->teamLayerCount = nl;
         const char* env = getenv("NSG_TEAM_TRUNK");
         ev->teamEnabled = (env && env[0] == '0') ? 0 : 1;
-        if (ev->teamEnabled && !ev->teamLockHeld) {
+    }
+    if ((ev->teamLayerCount > 0 && ev->teamEnabled) || ev->coopEnabled) {
+        if (!ev->teamLockHeld) {
             if (teamDeviceLock(ev->gpu)) {
                 ev->teamLockHeld = true;
-            } else { // another process runs team launches on this device
+            } else { // another process runs persistent launches with hand-offs on this device
                 ev->teamEnabled = 0;
+                ev->coopEnabled = 0;
                 ev->teamLockedOut = 1;
             }
         }
@@ -1078,7 +1165,8 @@ int enqueueOutputs(nsg_evaluator* ev) {
 int teamRecover(nsg_evaluator* ev) {
     if (!ev->teamStatusHost || *ev->teamStatusHost == 0) return NSG_OK;
     *ev->teamStatusHost = 0;
-    ev->teamEnabled = 0;
+    if (ev->lastPersistent == 2) ev->coopEnabled = 0; // the cooperative trunk gave up: the per-layer kernels of the same plan
+    else ev->teamEnabled = 0;
     ++ev->teamFallbacks;
     releaseTeamToken(ev);
     if (ev->pending.kind == 0 || ev->pending.n == 0 || !ev->teamLast) return NSG_OK;
@@ -1120,6 +1208,7 @@ static int checkTuningEnv() {
         {"NSG_SLAB_SPLIT", 0, 1, "slab-split two-board tiles at mid batches"},
         {"NSG_KSPLIT3", 0, 1, "three-way K split of 192-channel nets at small and mid batches"},
         {"NSG_TEAM_TRUNK", 0, 1, "team trunk for the smallest batches"},
+        {"NSG_COOP_TRUNK", 0, 1, "cooperative trunk for the two-way K split of the mid batches"},
         {"NSG_TEAM_MAX_BATCH", 0, 16, "largest batch that runs the team trunk"},
         {"NSG_TEAM_FAULT_LAUNCHES", 0, 1000000, "test hook: team launches made one workgroup short"},
         {"NSG_TEAM_MEMBERS", 16, 96, "most workgroups per board of the team trunk on a 256-channel net: 16, 32, 48 or 96 "
@@ -1709,6 +1798,13 @@ int nsg_get_team_stats(nsg_evaluator* ev, int* enabled, int* members_last, uint6
     if (enabled) *enabled = (ev->teamLayerCount > 0 && ev->teamEnabled) ? 1 : (ev->teamLockedOut ? -1 : 0);
     if (members_last) *members_last = ev->teamLastMembers;
     if (fallbacks) *fallbacks = ev->teamFallbacks;
+    return NSG_OK;
+}
+
+int nsg_get_last_launch_kind(nsg_evaluator* ev, int* kind, int* coop_enabled) {
+    if (!ev) return fail(NSG_E_INVALID, "null evaluator");
+    if (kind) *kind = ev->lastPersistent;
+    if (coop_enabled) *coop_enabled = ev->coopEnabled ? 1 : (ev->teamLockedOut ? -1 : 0);
     return NSG_OK;
 }
 

@@ -1137,3 +1137,59 @@ def test_f16m6_three_way_k_split_192_channels(nsg, oracle, monkeypatch, batch):
     po, vo, do = old.compute_blocking(bb)
     assert old.last_plan()["k_split"] != 3
     assert float(np.abs(p - po).max()) < TOL
+
+
+@pytest.mark.parametrize("batch", [65, 101, 128])
+def test_cooperative_trunk_mid_batches(nsg, oracle, monkeypatch, batch):
+    """65 ... CUs/2 boards of a 256-channel f16m6 net: the two-way K split (two workgroups per board, 128 channels
+    each) as ONE launch for all 3x3 layers -- a workgroup waits for its board's other workgroup only, not for the
+    slowest of the whole grid 41 times per forward (mfma_tile.h, coopTrunkKernel).  Same tile code as the per-layer
+    kernels: bit-identical to them (NSG_COOP_TRUNK=0), against the oracle, deterministic and slot-independent."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    if not (batch * 2 <= cus < batch * 4):
+        pytest.skip("batch range of this plan depends on the CU count")
+    ev, blob = make(nsg, 3, 256, batch, precision="f16m6", seed=610)
+    bb = nsg.synth.random_batch(batch, 86, seed=611, garbage=True)
+    p, v, d = ev.compute_blocking(bb)
+    assert ev.last_launch_kind() == ("coop", 1) and ev.last_plan()["k_split"] == 2, (ev.last_launch_kind(), ev.last_plan())
+    assert ev.team_stats()["fallbacks"] == 0
+    idx = sorted({0, batch // 2, batch - 1})
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
+    for _ in range(3):  # launch after launch, and with the boards in other slots
+        p2, v2, d2 = ev.compute_blocking(bb[::-1].copy())
+        np.testing.assert_array_equal(p2[::-1], p)
+        np.testing.assert_array_equal(v2[::-1], v)
+    ev.upload_features(bb)  # device-resident, queued behind each other
+    for _ in range(4):
+        ev.forward_resident(batch)
+    pr, vr, dr = ev.download_outputs(batch)
+    np.testing.assert_array_equal(pr, p)
+    monkeypatch.setenv("NSG_COOP_TRUNK", "0")
+    per, _ = make(nsg, 3, 256, batch, precision="f16m6", seed=610)
+    pp, vp, dp = per.compute_blocking(bb)
+    assert per.last_launch_kind() == ("per_layer", 0) and per.last_plan()["k_split"] == 2
+    np.testing.assert_array_equal(pp, p)
+    np.testing.assert_array_equal(vp, v)
+    np.testing.assert_array_equal(dp, d)
+
+
+def test_cooperative_trunk_gives_up_and_the_batch_is_rerun(nsg, oracle, monkeypatch):
+    """The cooperative trunk's safety net (the team trunk's: test_team_trunk_gives_up_and_the_batch_is_rerun): a
+    member that never publishes (test hook) makes its board's other member give up; the waiting call re-runs the batch
+    on the per-layer kernels and succeeds, later batches keep to them."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    batch = max(2, cus // 2 - 5)
+    monkeypatch.setenv("NSG_TEAM_FAULT_LAUNCHES", "1")
+    ev, blob = make(nsg, 2, 256, batch, precision="f16m6", seed=620)
+    bb = nsg.synth.random_batch(batch, 86, seed=621)
+    p, v, d = ev.compute_blocking(bb)
+    assert ev.team_stats()["fallbacks"] == 1 and ev.last_launch_kind() == ("per_layer", 0)
+    idx = [0, batch - 1]
+    check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
+    p2, v2, d2 = ev.compute_blocking(bb)
+    np.testing.assert_array_equal(p2, p)
+    assert ev.team_stats()["fallbacks"] == 1 and ev.stats()["batches"] == 2
