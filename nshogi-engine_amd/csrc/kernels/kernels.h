@@ -129,9 +129,10 @@ hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
 // Cooperative trunk (mfma_tile.h, coopTrunkKernel): every 3x3 layer of a mid batch whose boards are shared by several
 // workgroups (K-split plans) in ONE launch; workgroups of a board hand their output slices to each other through
 // agent-scope stores / loads and one flag per (board, member) in `flags` (batch x members unsigned, zeroed before the
-// launch).  kF16m6, 256 channels, the two-way K split (65 ... CUs/2 boards).  All batch x members workgroups must be
+// launch).  kF16m6: 256 channels, the two-way K split (65 ... CUs/2 boards) and the four-way K split with its row
+// groups (17 ... CUs/4); 192 channels, the three-way K split (17 ... CUs/3).  All batch x members workgroups must be
 // resident at once.  `status`: host-mapped int raised when a bounded spin runs out.
-bool canRunCoopTrunk(int cout, int stemKdim, int prec, const ConvPlan& plan);
+bool canRunCoopTrunk(int cout, int stemKdim, int prec, const ConvPlan& plan, bool* firstSeparate = nullptr);
 int coopMembers(int cout, const ConvPlan& plan); // workgroups per board
 // (faultBoard >= 0: test hook -- that board's second member leaves at once, so its first waits in vain)
 hipError_t launchCoopTrunk(const void* devLayers, int nLayers, int batch, int cout, int prec, const ConvPlan& plan,

@@ -1843,14 +1843,15 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
 // All gridDim.x * gridDim.y workgroups must be resident (the host checks the grid against the CU count and keeps one
 // such launch per device); every spin is bounded (~1 s): a member that gives up raises the host-mapped `status` and
 // the launch unwinds; the host re-runs the batch on the per-layer kernels (nsg_capi.hip, teamRecover).
-template <int PREC, int NFRAG, int NWAVES, int KS>
+template <int PREC, int NFRAG, int NWAVES, int MS, int KS>
 __global__ __launch_bounds__(NWAVES * 64, 1) void coopTrunkKernel(const Args* __restrict__ layers, int nLayers,
                                                                   unsigned* flags, int* status, int faultBoard) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = Geom<kConv, 1, NWAVES, 8>;
-    if ((int)blockIdx.x == faultBoard && blockIdx.y == 1) return; // (test hook: this member never publishes)
+    // a board's members: gridDim.y channel groups x gridDim.z row groups (K split AND row split: tileBody, kRowWG)
+    const int members = (int)(gridDim.y * gridDim.z), me = (int)(blockIdx.z * gridDim.y + blockIdx.y);
+    if ((int)blockIdx.x == faultBoard && me == 1) return; // (test hook: this member never publishes)
     int* gaveUp = reinterpret_cast<int*>(smem + G::kLdsAlloc); // one int behind everything tileBody uses
-    const int members = (int)gridDim.y, me = (int)blockIdx.y;
     unsigned* mine = flags + (size_t)blockIdx.x * members;
     if (threadIdx.x == 0) *gaveUp = 0;
     for (int l = 0; l < nLayers; ++l) {
@@ -1871,25 +1872,33 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void coopTrunkKernel(const Args* __
             if (*gaveUp) return;
         }
         const Args A = layers[l];
-        if (A.res) tileBody<PREC, kConv, 1, NFRAG, NWAVES, 1, 1, KS, 1, 0, true>(A, smem, true);
-        else tileBody<PREC, kConv, 1, NFRAG, NWAVES, 0, 1, KS, 1, 0, true>(A, smem, true);
+        if (A.res) tileBody<PREC, kConv, 1, NFRAG, NWAVES, 1, MS, KS, 1, 0, true>(A, smem, true);
+        else tileBody<PREC, kConv, 1, NFRAG, NWAVES, 0, MS, KS, 1, 0, true>(A, smem, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its write-through stores have left
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(mine + me, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <int PREC, int NFRAG, int NWAVES, int KS>
+template <int PREC, int NFRAG, int NWAVES, int MS, int KS>
 hipError_t launchCoopOne(const Args* layers, int nLayers, int boards, int cout, unsigned* flags, int* status, hipStream_t stream,
                          int faultBoard) {
     using G = Geom<kConv, 1, NWAVES, 8>;
-    constexpr int kChanGroups = NWAVES / KS;
+    constexpr bool kRowWG = (MS > 1 && KS > 1);
+    constexpr int kChanGroups = NWAVES / (kRowWG ? KS : MS * KS);
     const int gy = cout / (kChanGroups * NFRAG * 16);
-    if (gy < 1 || gy * kChanGroups * NFRAG * 16 != cout || gy > 64) return hipErrorInvalidValue;
-    auto k = coopTrunkKernel<PREC, NFRAG, NWAVES, KS>;
-    const hipError_t err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc + 16);
-    if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k, dim3(boards, gy), dim3(G::kThreads), G::kLdsAlloc + 16, stream, layers, nLayers, flags, status, faultBoard);
+    if (gy < 1 || gy * kChanGroups * NFRAG * 16 != cout || gy * (kRowWG ? MS : 1) > 64) return hipErrorInvalidValue;
+    auto k = coopTrunkKernel<PREC, NFRAG, NWAVES, MS, KS>;
+    static std::atomic<int> attrDevMask{0}; // per kernel instantiation: devices whose attribute is set
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attrDevMask.load() & (1 << dev))) {
+        const hipError_t err = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLdsAlloc + 16);
+        if (err != hipSuccess) return err;
+        attrDevMask.fetch_or(1 << dev);
+    }
+    hipLaunchKernelGGL(k, dim3(boards, gy, kRowWG ? MS : 1), dim3(G::kThreads), G::kLdsAlloc + 16, stream, layers, nLayers, flags,
+                       status, faultBoard);
     return hipGetLastError();
 }
 

@@ -153,13 +153,24 @@ hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
     return hipErrorInvalidValue;
 }
 
-bool canRunCoopTrunk(int cout, int stemKdim, int prec, const ConvPlan& plan) {
-    // every layer, the stem included, must run the same kernel: two K halves of whole chunk pairs
-    return prec == kF16m6 && cout == 256 && stemKdim % 128 == 0 && stemKdim <= 256 && plan.nb == 1 && plan.nfrag == kNfrag &&
-           plan.nwaves == 4 && plan.ksplit == 2 && plan.msplit == 1 && plan.sslab == 1;
+// The K-split plans of an f16m6 evaluator.  *firstSeparate: the stem has fewer chunk pairs than the plan splits K by and
+// runs another kernel (its own launch, ahead of the cooperative one, which then starts at the first residual layer).
+bool canRunCoopTrunk(int cout, int stemKdim, int prec, const ConvPlan& plan, bool* firstSeparate) {
+    if (prec != kF16m6 || plan.nb != 1 || plan.nfrag != kNfrag || plan.sslab != 1) return false;
+    const bool rows = plan.msplit == 1 || plan.msplit == 2 || plan.msplit == 3 || plan.msplit == 6;
+    bool sep = false, ok = false;
+    if (cout == 256 && plan.nwaves == 4 && plan.ksplit == 2 && plan.msplit == 1) { ok = true; sep = !(stemKdim % 128 == 0 && stemKdim <= 256); }
+    else if (cout == 256 && plan.nwaves == 4 && plan.ksplit == 4 && rows) { ok = true; sep = !(stemKdim == 256); }
+    else if (cout == 192 && plan.nwaves == 3 && plan.ksplit == 3 && rows) { ok = true; sep = !(stemKdim == 192); }
+    if (firstSeparate) *firstSeparate = sep;
+    return ok;
 }
 
-int coopMembers(int cout, const ConvPlan& plan) { return cout / ((plan.nwaves / plan.ksplit) * plan.nfrag * 16); }
+int coopMembers(int cout, const ConvPlan& plan) {
+    const bool rowWG = plan.msplit > 1 && plan.ksplit > 1;
+    const int chanGroups = plan.nwaves / (rowWG ? plan.ksplit : plan.msplit * plan.ksplit);
+    return cout / (chanGroups * plan.nfrag * 16) * (rowWG ? plan.msplit : 1);
+}
 
 hipError_t launchCoopTrunk(const void* devLayers, int nLayers, int batch, int cout, int prec, const ConvPlan& plan,
                            unsigned* flags, int* status, hipStream_t stream, int faultBoard) {

@@ -341,6 +341,7 @@ struct nsg_evaluator {
     // trunk's device token (both need every workgroup of their grid resident), status word and recovery.
     DevBuf coopFlags;           // [batchMax][members] unsigned, zeroed before every launch
     int coopEnabled = 1;
+    int coopForced = 0;         // NSG_COOP_TRUNK=1: wherever a plan allows it; unset: where it measured faster (enqueueForward)
     int lastPersistent = 0;     // what the most recent forward ran: 0 per-layer / persistent-without-hand-off, 1 team trunk, 2 cooperative trunk
     int teamFaultLaunches = 0;  // NSG_TEAM_FAULT_LAUNCHES (test hook): this many team launches are made ONE WORKGROUP SHORT,
                                 // so that the team waits in vain, gives up and the recovery path runs
@@ -622,13 +623,20 @@ int enqueueCoop(nsg_evaluator* ev, int B, const nsg::ConvPlan& plan, hipStream_t
     {
         Range r("nsg.trunk");
         const int members = nsg::coopMembers(ev->F, plan);
+        bool stemFirst = false;
+        (void)nsg::canRunCoopTrunk(ev->F, ev->cpad, prec, plan, &stemFirst);
         NSG_HIP(hipMemsetAsync(ev->coopFlags.p, 0, (size_t)B * members * sizeof(unsigned), s));
+        if (stemFirst) // the stem has fewer chunk pairs than the plan splits K by: its own launch, the plan's stem kernel
+            NSG_HIP(nsg::launchConv3x3(ev->planes.p, ev->W->stem.w.p, (const float*)ev->W->stem.bias.p, nullptr, ev->act[0].p, B,
+                                       ev->cpad, ev->F, 1, ev->W->stem.accScale, prec, plan, s, nullptr, false));
+        const int l0 = stemFirst ? 1 : 0;
         if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
         // (test hook NSG_TEAM_FAULT_LAUNCHES: the last board's second member leaves at once and never publishes)
         const int faultBoard = ev->teamFaultLaunches > 0 ? B - 1 : -1;
         if (faultBoard >= 0) --ev->teamFaultLaunches;
-        NSG_HIP(nsg::launchCoopTrunk(ev->trunkLayers.p, ev->trunkLayerCount, B, ev->F, prec, plan,
-                                     (unsigned*)ev->coopFlags.p, ev->teamStatusDev, s, faultBoard));
+        NSG_HIP(nsg::launchCoopTrunk((const unsigned char*)ev->trunkLayers.p + (size_t)l0 * nsg::trunkLayerBytes(),
+                                     ev->trunkLayerCount - l0, B, ev->F, prec, plan, (unsigned*)ev->coopFlags.p,
+                                     ev->teamStatusDev, s, faultBoard));
         NSG_HIP(hipEventRecord(ev->teamDone, s));
         if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
     }
@@ -851,7 +859,11 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     if (ev->coopEnabled && ev->teamStatusDev && ev->coopFlags.p && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 &&
         ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && ev->useTrunkKernel != 1 && mx && ev->chainMinBatch <= 0 &&
         ev->chainDelayUs == 0 && nsg::canRunCoopTrunk(ev->F, ev->cpad, ev->prec, plan) &&
-        (long)B * nsg::coopMembers(ev->F, plan) <= ev->prop.multiProcessorCount) {
+        (long)B * nsg::coopMembers(ev->F, plan) <= ev->prop.multiProcessorCount &&
+        // measured (profiles/r04/o_cooperative_trunk_all_k_split_plans_sweep.txt): 256 channels with up to eight members
+        // per board +1...8 % (24-128 boards), twelve members (17-21 boards) -3 %; 192 channels (13-us layers, three
+        // members + row groups) -2...-8 % but for 85 boards: those keep their per-layer launches unless forced
+        (ev->coopForced || (ev->F == 256 && nsg::coopMembers(ev->F, plan) <= 8))) {
         int rc;
         {
             TeamTokenGuard token(ev);
@@ -1070,8 +1082,9 @@ int finishLoad(nsg_evaluator* ev, std::shared_ptr<NetWeights> W) {
     {   // cooperative trunk (mid batches): flags of (board, member)
         const char* env = getenv("NSG_COOP_TRUNK");
         ev->coopEnabled = (env && env[0] == '0') ? 0 : 1;
-        if (prec == nsg::kF16m6 && N.F == 256 && ev->coopEnabled) {
-            if ((rc = ev->coopFlags.alloc((size_t)ev->batchMax * 8 * sizeof(unsigned), true))) return rc;
+        ev->coopForced = (env && env[0] == '1') ? 1 : 0;
+        if (prec == nsg::kF16m6 && (N.F == 256 || N.F == 192) && N.blocks >= 1 && ev->coopEnabled) {
+            if ((rc = ev->coopFlags.alloc((size_t)ev->batchMax * 24 * sizeof(unsigned), true))) return rc;
         } else {
             ev->coopEnabled = 0;
         }

@@ -1139,21 +1139,36 @@ def test_f16m6_three_way_k_split_192_channels(nsg, oracle, monkeypatch, batch):
     assert float(np.abs(p - po).max()) < TOL
 
 
-@pytest.mark.parametrize("batch", [65, 101, 128])
-def test_cooperative_trunk_mid_batches(nsg, oracle, monkeypatch, batch):
-    """65 ... CUs/2 boards of a 256-channel f16m6 net: the two-way K split (two workgroups per board, 128 channels
-    each) as ONE launch for all 3x3 layers -- a workgroup waits for its board's other workgroup only, not for the
-    slowest of the whole grid 41 times per forward (mfma_tile.h, coopTrunkKernel).  Same tile code as the per-layer
-    kernels: bit-identical to them (NSG_COOP_TRUNK=0), against the oracle, deterministic and slot-independent."""
+@pytest.mark.parametrize("channels,batch", [(256, 65), (256, 101), (256, 128), (256, 17), (256, 24), (256, 40), (256, 64),
+                                            (192, 17), (192, 30), (192, 64), (192, 85)])
+def test_cooperative_trunk_mid_batches(nsg, oracle, monkeypatch, channels, batch):
+    """The K-split plans of an f16m6 evaluator -- several workgroups per board: two 128-channel halves at 65 ... CUs/2
+    boards, four 64-channel groups (x 1 / 2 / 3 / 6 row groups) at 17 ... CUs/4, three (192 channels) at 17 ... CUs/3 --
+    as ONE launch for all 3x3 layers: a workgroup waits for the other workgroups of ITS board only, not for the slowest of
+    the whole grid 41 times per forward (mfma_tile.h, coopTrunkKernel; the stem, which has fewer chunk pairs than the
+    four- and three-way splits need, keeps its own launch).  Same tile code as the per-layer kernels: bit-identical to
+    them (NSG_COOP_TRUNK=0), against the oracle, deterministic and slot-independent."""
     probe = nsg.Evaluator(0, 1, 86)
     cus = probe.info()["compute_units"]
     del probe
-    if not (batch * 2 <= cus < batch * 4):
-        pytest.skip("batch range of this plan depends on the CU count")
-    ev, blob = make(nsg, 3, 256, batch, precision="f16m6", seed=610)
+    if channels == 256:
+        ks = 4 if batch * 4 <= cus else 2
+        if ks == 2 and not (batch * 2 <= cus):
+            pytest.skip("batch range of this plan depends on the CU count")
+    else:
+        ks = 3
+        if batch * 3 > cus:
+            pytest.skip("batch range of this plan depends on the CU count")
+    # by default the cooperative launch is taken where it measured faster: 256 channels, at most eight members per board
+    auto, _ = make(nsg, 3, channels, batch, precision="f16m6", seed=610)
+    auto.compute_blocking(nsg.synth.random_batch(batch, 86, seed=611, garbage=True))
+    members = {2: 2, 3: 3, 4: 4}[ks] * auto.last_plan()["row_split"]
+    assert auto.last_launch_kind()[0] == ("coop" if channels == 256 and members <= 8 else "per_layer"), (auto.last_launch_kind(), members)
+    monkeypatch.setenv("NSG_COOP_TRUNK", "1")  # ... here: every plan that has a cooperative form
+    ev, blob = make(nsg, 3, channels, batch, precision="f16m6", seed=610)
     bb = nsg.synth.random_batch(batch, 86, seed=611, garbage=True)
     p, v, d = ev.compute_blocking(bb)
-    assert ev.last_launch_kind() == ("coop", 1) and ev.last_plan()["k_split"] == 2, (ev.last_launch_kind(), ev.last_plan())
+    assert ev.last_launch_kind() == ("coop", 1) and ev.last_plan()["k_split"] == ks, (ev.last_launch_kind(), ev.last_plan())
     assert ev.team_stats()["fallbacks"] == 0
     idx = sorted({0, batch // 2, batch - 1})
     check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
@@ -1167,9 +1182,9 @@ def test_cooperative_trunk_mid_batches(nsg, oracle, monkeypatch, batch):
     pr, vr, dr = ev.download_outputs(batch)
     np.testing.assert_array_equal(pr, p)
     monkeypatch.setenv("NSG_COOP_TRUNK", "0")
-    per, _ = make(nsg, 3, 256, batch, precision="f16m6", seed=610)
+    per, _ = make(nsg, 3, channels, batch, precision="f16m6", seed=610)
     pp, vp, dp = per.compute_blocking(bb)
-    assert per.last_launch_kind() == ("per_layer", 0) and per.last_plan()["k_split"] == 2
+    assert per.last_launch_kind() == ("per_layer", 0) and per.last_plan() == ev.last_plan()
     np.testing.assert_array_equal(pp, p)
     np.testing.assert_array_equal(vp, v)
     np.testing.assert_array_equal(dp, d)
