@@ -1731,7 +1731,7 @@ int nsg_download_planes_raw(nsg_evaluator* ev, size_t batch_size, void* dst, siz
     if (rc) return rc;
     if (!ev->trunkOut) return fail(NSG_E_INVALID, "no forward has run yet");
     if ((rc = syncAndRecover(ev))) return rc;
-    if (ev->teamLast)
+    if (ev->teamLast && ev->lastPersistent == 1)
         return fail(NSG_E_INVALID, "the last forward ran the team trunk, which decodes the bitboards inside its first layer: "
                                    "there is no plane buffer for it (NSG_TEAM_TRUNK=0 keeps the per-layer kernels)");
     if (!dst || !row_bytes) return fail(NSG_E_INVALID, "null argument");
