@@ -119,6 +119,7 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
 // and reused for every batch size.  Needs cout == nwaves*64 (one workgroup covers all
 // output channels of its boards); canRunTrunk() says whether a plan qualifies.
 size_t trunkLayerBytes();
+size_t trunkLayerStampsOffset(); // (diagnostic builds) byte offset of a layer's stamp pointer inside its list entry
 void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfrag,
                     const float* bias, const void* residual, void* y, int cin,
                     int cout, int relu, float accScale, bool outF16x3 = false);
@@ -133,6 +134,7 @@ hipError_t launchTrunk(const void* devLayers, int nLayers, int batch, int prec,
 // groups (17 ... CUs/4); 192 channels, the three-way K split (17 ... CUs/3).  All batch x members workgroups must be
 // resident at once.  `status`: host-mapped int raised when a bounded spin runs out.
 bool canRunCoopTrunk(int cout, int stemKdim, int prec, const ConvPlan& plan, bool* firstSeparate = nullptr);
+bool coopFits(int boards, int members, int computeUnits); // every workgroup of the launch resident at once (per XCD)
 int coopMembers(int cout, const ConvPlan& plan); // workgroups per board
 // (faultBoard >= 0: test hook -- that board's second member leaves at once, so its first waits in vain)
 hipError_t launchCoopTrunk(const void* devLayers, int nLayers, int batch, int cout, int prec, const ConvPlan& plan,

@@ -68,6 +68,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 enum Mode { kConv = 0, kHeads = 1, kDense = 2 };
 
+// The cooperative trunk's hand-off: plain stores kept in the XCD's L2, the members of a board on one XCD (coopTrunkKernel)
+#ifdef NSG_COOP_SC1_STORES // A/B partner build: write-through stores, no placement requirement
+constexpr bool kCoopSameXcd = false;
+#else
+constexpr bool kCoopSameXcd = true;
+#endif
+
 // SIZE = boards per workgroup (kConv) or 16-row fragments per workgroup.
 template <int MODE, int SIZE, int NWAVES, int NBUF = 2>
 struct Geom {
@@ -76,6 +83,13 @@ struct Geom {
     static constexpr int kMF = (kRows + 15) / 16;
     static constexpr int kEntries = kBoards ? SIZE * 110 + 24 : kMF * 16;
     static constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
+    // Plane p of a chunk buffer starts (p & 3) * kSkew bytes into its slot.  A staging store writes, per group of
+    // eight lanes, the four 16-byte pieces of two neighbouring rows (the lane order that makes the global load of those
+    // pieces one 64-byte segment per lane quad): without the skew the four pieces of a row -- same entry, four planes,
+    // planes a multiple of 128 bytes apart -- fall on the same banks (4-way conflict on every ds_write_b128); skewed by
+    // 32 bytes each, the eight pieces of a group cover eight different 16-byte slots.
+    static constexpr int kSkew = kBoards ? 32 : 0;
+    static_assert(kEntries * 16 + 3 * kSkew <= kPlane, "the skewed planes must fit their slots");
     static constexpr int kBuf = 8 * kPlane;  // one 128-byte channel chunk
     static constexpr int kLds = NBUF * kBuf; // double buffered (kF16m8: four buffers = two chunk pairs)
     // LDS the epilogue may stage through: a two-board tile has the CU to itself (its waves need the
@@ -140,11 +154,11 @@ __device__ __forceinline__ void zeroHalo(unsigned char* smem, int tid) {
             int plane = pl * kWavesN + wave;
             plane = plane < kPlanes ? plane : kPlanes - 1;
             if constexpr (SHIFT) {
-                unsigned char* z = smem + e * 16 + (size_t)plane * G::kPlane + ((plane & 7) == 7 ? 8 : 0);
+                unsigned char* z = smem + e * 16 + (size_t)plane * G::kPlane + (plane & 3) * G::kSkew + ((plane & 7) == 7 ? 8 : 0);
                 *reinterpret_cast<u32x2*>(z) = u32x2{0u, 0u};
                 *reinterpret_cast<u32x2*>(z + 8) = u32x2{0u, 0u};
             } else {
-                *reinterpret_cast<u32x4*>(smem + e * 16 + (size_t)plane * G::kPlane) = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(smem + e * 16 + (size_t)plane * G::kPlane + (plane & 3) * G::kSkew) = u32x4{0u, 0u, 0u, 0u};
             }
         }
     }
@@ -475,8 +489,9 @@ struct StepSeq {
 // it once.  All 2*KS*... chunk tiles of the board are resident in LDS at once (eight image buffers for
 // 256 channels), so the loop has no staging and no barriers.
 // COOP (coopTrunkKernel): the workgroup's input rows were written by OTHER workgroups of the same launch -- every load
-// of activations (input tiles, residual) is an agent-scope (sc1) buffer load that never hits this CU's L1, every output
-// store a write-through (sc1) buffer store.
+// of activations (input tiles, residual) is an agent-scope (sc1) buffer load that never hits this CU's L1; every output
+// store is a plain store that stays in the XCD's L2 (kCoopSameXcd: the members of a board share an XCD, verified at run
+// time) or, in the -DNSG_COOP_SC1_STORES build, a write-through (sc1) store.
 template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1, int SS = 1, int PART = 0, bool COOP = false>
 __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
     static_assert(!COOP || (isMx(PREC) && MODE == kConv && NFRAG == 4), "cooperative trunk: MX conv tiles");
@@ -536,18 +551,23 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     // kConv buffers are sized for whole workgroups; flat modes clamp rows.
     const size_t lastRow = G::kBoards ? ~(size_t)0 : (size_t)(A.totalRows - 1);
 
-    // staging: item k of this wave moves 16 rows x 4 chunks (16 B per lane)
+    // staging: item k of this wave moves 16 rows x 4 pieces (16 B per lane) = one 64-byte half of a channel chunk per row.
+    // Lane order of the move: piece = lane & 3, row = lane >> 2 -- a lane QUAD reads one contiguous 64-byte segment.
+    // (In the MFMA operand order -- row = lane & 15, piece = lane >> 4 -- every quad read four different rows, four
+    // cache lines: the texture unit took ~47 cycles per 1-KiB wave load instead of 16, and the 24 tile loads a wave of
+    // a K-split tile issues at the top of every layer took 4.5k cycles to ISSUE: profiles/r04/w_*, y_*.)
+    const int sli = lane >> 2, sg = lane & 3;
     size_t srcOff[G::kItems];
     int dstOff[G::kItems];
     bool itemOk[G::kItems];
 #pragma unroll
     for (int k = 0; k < G::kItems; ++k) {
         const int wid = wave + k * NWAVES;
-        const int m = (wid >> 1) * 16 + li;
+        const int m = (wid >> 1) * 16 + sli;
         itemOk[k] = (wid < 2 * G::kMF) && (m < G::kRows);
         size_t grow = row0 + (itemOk[k] ? m : 0);
         if (grow > lastRow) grow = lastRow;
-        srcOff[k] = grow * (size_t)A.kdim * ES + ((wid & 1) * 4 + g) * 16 + (size_t)kc0 * 128;
+        srcOff[k] = grow * (size_t)A.kdim * ES + ((wid & 1) * 4 + sg) * 16 + (size_t)kc0 * 128;
     }
     // MX conv tiles read their input through a buffer descriptor on the workgroup's own boards: a 32-bit lane offset
     // inside the tile + a wave-uniform chunk offset, instead of a 64-bit address per item (the loop has no vector
@@ -592,26 +612,27 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     constexpr int kResChunks = 8;
     u32x4 stAll[kResident ? kResChunks : 1][G::kItems];
     if constexpr (kResident) {
+        // (a chunk the layer does not have -- the stem's, a 192-channel layer's last two -- is requested past the end of
+        // the descriptor and comes back as zeros: one select on the lane offset instead of a branch around every load)
 #pragma unroll
         for (int c = 0; c < kResChunks; ++c)
 #pragma unroll
-            for (int k = 0; k < G::kItems; ++k) {
-                stAll[c][k] = u32x4{0u, 0u, 0u, 0u};
-                if (__builtin_expect(c < nkc, 1)) stAll[c][k] = tileLoad(k, c);
-            }
+            for (int k = 0; k < G::kItems; ++k)
+                stAll[c][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    xrs, c < nkc ? srcRel[k] : 0x7ffffff0, c * 128, COOP ? 16 /* sc1 */ : 0));
         __builtin_amdgcn_sched_barrier(0);
         NSG_STAMP(4); // (diagnostic builds) every tile load issued
     }
 #pragma unroll
     for (int k = 0; k < G::kItems; ++k) {
         const int wid = wave + k * NWAVES;
-        const int c = (wid & 1) * 4 + g;
-        const int mm = itemOk[k] ? (wid >> 1) * 16 + li : 0;
+        const int c = (wid & 1) * 4 + sg;
+        const int mm = itemOk[k] ? (wid >> 1) * 16 + sli : 0;
         // masked lanes store to their own trash slot behind both buffers (one shared slot made
         // every masked store a 64-way same-address conflict that stalled the whole LDS): the store
         // stays unconditional, so st[] stays in registers
         // (bit select, not ?: -- the compiler turned the conditional into a far out-of-line block per item)
-        const int okOff = c * G::kPlane + entryOfRow<G::kBoards>(mm) * 16 + ((kShiftLo && c == 7) ? 8 : 0), okMask = -(int)itemOk[k];
+        const int okOff = c * G::kPlane + sg * G::kSkew + entryOfRow<G::kBoards>(mm) * 16 + ((kShiftLo && c == 7) ? 8 : 0), okMask = -(int)itemOk[k];
         dstOff[k] = (okOff & okMask) | ((G::kLds + lane * 16) & ~okMask);
     }
 
@@ -640,9 +661,9 @@ _Pragma("unroll") \
         if constexpr (G::kBoards) { \
             const int p = kPerm ? (eok ? 24 + eb * 110 + (ey + 1) * 10 + ex : 11) \
                                 : ((m < G::kRows) ? entryOfRow<true>(m) : 11); \
-            abase[f] = g * G::kPlane + (p - 11) * 16; \
+            abase[f] = g * (G::kPlane + G::kSkew) + (p - 11) * 16; \
         } else { \
-            abase[f] = g * G::kPlane + m * 16; \
+            abase[f] = g * (G::kPlane + G::kSkew) + m * 16; \
         } \
     }
     if constexpr (!kPerm) { NSG_COMPUTE_ABASE }
@@ -715,7 +736,8 @@ _Pragma("unroll") \
         static_assert(kWriteStepB < kBarStep, "tile staging order");
         auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
         // MX operand of lane (li, g): 32 fp8 bytes of chunk g>>1 (A / B buffer); g&1 ? lo bytes : hi bytes
-        const int offp8 = (g >> 1) * G::kBuf + (4 + 2 * (g & 1) - g) * G::kPlane;
+        // (planes 4 + 2 * (g & 1) and the one behind it; abase holds plane g and its skew)
+        const int offp8 = (g >> 1) * G::kBuf + (4 + 2 * (g & 1) - g) * G::kPlane + (2 * (g & 1) - g) * G::kSkew;
         // Weight records of a chunk pair, per tap: [main A: nft KiB][main B: nft KiB][MX slab].  kF16m8: the MX slab is
         // two 1-KiB records per fragment (32 fp8 bytes per lane).  kF16m6 (kPackX): per group of four fragments
         // [4 x 1 KiB: code dwords 0-3][4 x 512 B: code dwords 4-5][256 B: one dword per lane = the four fragments'
@@ -821,7 +843,7 @@ _Pragma("unroll") \
         // instruction per MX step does not.  What the loop is short of is LDS issue, not vector issue.
         constexpr bool kSplitRead = kShiftLo && OS::kX > 0;
         // (without the split read, plane 7's shift still applies: its piece is read at + 8)
-        const int offB = offp8 + G::kPlane + 8 * (g & 1);
+        const int offB = offp8 + G::kPlane + G::kSkew + 8 * (g & 1);
         u32x4 aw[kWin][kSplitRead ? 1 : 2];
         [[maybe_unused]] u32x2 aw45[kSplitRead ? kWin : 1];
         [[maybe_unused]] uint32_t awS[kSplitRead ? kWin : 1];
@@ -841,7 +863,7 @@ _Pragma("unroll") \
                 } else if constexpr (kShiftLo) {                                                  \
                     aw[(QQ) % kWin][kSplitRead ? 0 : 1] = *reinterpret_cast<const u32x4*>(ap2_);  \
                 } else {                                                                          \
-                    aw[(QQ) % kWin][kSplitRead ? 0 : 1] = *reinterpret_cast<const u32x4*>(ap_ + G::kPlane); \
+                    aw[(QQ) % kWin][kSplitRead ? 0 : 1] = *reinterpret_cast<const u32x4*>(ap_ + G::kPlane + G::kSkew); \
                 }                                                                                 \
             } else {                                                                              \
                 aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(                             \
@@ -1425,7 +1447,7 @@ _Pragma("unroll") \
             else return *reinterpret_cast<const u32x4*>(resBase + off_);
         };
         auto outStore = [&](size_t off_, const u32x4& v_) {
-            if constexpr (COOP) __builtin_amdgcn_raw_buffer_store_b128(v_, yRs, (int)off_, 0, 16);
+            if constexpr (COOP) __builtin_amdgcn_raw_buffer_store_b128(v_, yRs, (int)off_, 0, kCoopSameXcd ? 0 : 16);
             else *reinterpret_cast<u32x4*>(yBase + off_) = v_;
         };
         // edge-packed rows: per-lane offsets of the four rows (it = 0..3) this lane moves for fragment f
@@ -1843,40 +1865,66 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
 // All gridDim.x * gridDim.y workgroups must be resident (the host checks the grid against the CU count and keeps one
 // such launch per device); every spin is bounded (~1 s): a member that gives up raises the host-mapped `status` and
 // the launch unwinds; the host re-runs the batch on the per-layer kernels (nsg_capi.hip, teamRecover).
+//
+// Same-XCD hand-off (kCoopSameXcd, the default).  Write-through stores drop their lines from the XCD's L2, and a reader
+// -- same XCD or not -- then fetches them from the memory side (MI355X_MICROARCH, handoff-payload: 66-73 GB/s per
+// workgroup against 104-122 for lines kept in L2).  Workgroups are dealt round-robin over the eight XCDs in launch
+// order, so with gridDim.x a multiple of eight (the host pads it; workgroups past the last board leave at once) every
+// member of a board -- same blockIdx.x -- lands on ONE XCD, whose L2 all its CUs share: a plain store is in that L2
+// when its vmcnt has counted down (the L1 is write-through), and an sc1 load (L1 bypassed, L2 served) by any CU of the
+// XCD reads it there.  Placement is the hardware's habit, not a guarantee: every member publishes its XCC_ID in the top
+// byte of its flag and every poll checks it against the poller's own; a mismatch raises `status` = 2 like a timed-out
+// spin and the host re-runs the batch on the per-layer kernels and stops using this launch (nsg_capi.hip, teamRecover).
 template <int PREC, int NFRAG, int NWAVES, int MS, int KS>
-__global__ __launch_bounds__(NWAVES * 64, 1) void coopTrunkKernel(const Args* __restrict__ layers, int nLayers,
+__global__ __launch_bounds__(NWAVES * 64, 1) void coopTrunkKernel(const Args* __restrict__ layers, int nLayers, int boards,
                                                                   unsigned* flags, int* status, int faultBoard) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = Geom<kConv, 1, NWAVES, 8>;
+    if ((int)blockIdx.x >= boards) return; // (gridDim.x is padded to a multiple of eight)
     // a board's members: gridDim.y channel groups x gridDim.z row groups (K split AND row split: tileBody, kRowWG)
     const int members = (int)(gridDim.y * gridDim.z), me = (int)(blockIdx.z * gridDim.y + blockIdx.y);
     if ((int)blockIdx.x == faultBoard && me == 1) return; // (test hook: this member never publishes)
+    unsigned xcc = 0;
+    if constexpr (kCoopSameXcd) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        if (faultBoard == -2 && me == 1) xcc ^= 1u; // (test hook: a member that claims another XCD)
+    }
     int* gaveUp = reinterpret_cast<int*>(smem + G::kLdsAlloc); // one int behind everything tileBody uses
     unsigned* mine = flags + (size_t)blockIdx.x * members;
     if (threadIdx.x == 0) *gaveUp = 0;
     for (int l = 0; l < nLayers; ++l) {
+        // (the layer's arguments are requested BEFORE the poll: the scalar loads -- a cold line of the list every layer --
+        // return while the flags are waited for, instead of in front of the first tile request)
+        const Args A = layers[l];
+        asm volatile("" ::"s"(A.x), "s"(A.w), "s"(A.res), "s"(A.y), "s"(A.bias), "s"(A.kdim), "s"(A.cout), "s"(A.relu), "s"(A.accScale),
+                     "s"(A.outF16x3));
         if (l > 0) {
             if ((int)threadIdx.x < members && (int)threadIdx.x != me) { // one polling lane per neighbour (wave 0)
                 int spins = 0;
-                while (__hip_atomic_load(mine + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l) {
+                unsigned seen;
+                while (((seen = __hip_atomic_load(mine + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < (unsigned)l) {
                     if ((++spins & 255) == 0 &&
                         (spins > (1 << 21) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
                         __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         *gaveUp = 1;
+                        seen = xcc << 24;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(4);
+                }
+                if (kCoopSameXcd && (seen >> 24) != xcc) { // the neighbour runs on another XCD: its plain stores are not in this L2
+                    __hip_atomic_store(status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    *gaveUp = 1;
                 }
             }
             __syncthreads(); // the other waves load behind the polling wave's match
             if (*gaveUp) return;
         }
-        const Args A = layers[l];
         if (A.res) tileBody<PREC, kConv, 1, NFRAG, NWAVES, 1, MS, KS, 1, 0, true>(A, smem, true);
         else tileBody<PREC, kConv, 1, NFRAG, NWAVES, 0, MS, KS, 1, 0, true>(A, smem, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its write-through stores have left
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(mine + me, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(mine + me, (unsigned)(l + 1) | (xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1897,8 +1945,9 @@ hipError_t launchCoopOne(const Args* layers, int nLayers, int boards, int cout, 
         if (err != hipSuccess) return err;
         attrDevMask.fetch_or(1 << dev);
     }
-    hipLaunchKernelGGL(k, dim3(boards, gy, kRowWG ? MS : 1), dim3(G::kThreads), G::kLdsAlloc + 16, stream, layers, nLayers, flags,
-                       status, faultBoard);
+    // (gridDim.x padded to a multiple of eight: blockIdx.x picks the XCD, coopTrunkKernel)
+    hipLaunchKernelGGL(k, dim3((boards + 7) / 8 * 8, gy, kRowWG ? MS : 1), dim3(G::kThreads), G::kLdsAlloc + 16, stream, layers, nLayers,
+                       boards, flags, status, faultBoard);
     return hipGetLastError();
 }
 

@@ -115,6 +115,7 @@ hipError_t launchConv3x3(const void* x, const void* wfrag, const float* bias,
 }
 
 size_t trunkLayerBytes() { return sizeof(tile::Args); }
+size_t trunkLayerStampsOffset() { return offsetof(tile::Args, stamps); }
 
 void fillTrunkLayer(void* hostLayers, int index, const void* x, const void* wfrag,
                     const float* bias, const void* residual, void* y, int cin,
@@ -170,6 +171,14 @@ int coopMembers(int cout, const ConvPlan& plan) {
     const bool rowWG = plan.msplit > 1 && plan.ksplit > 1;
     const int chanGroups = plan.nwaves / (rowWG ? plan.ksplit : plan.msplit * plan.ksplit);
     return cout / (chanGroups * plan.nfrag * 16) * (rowWG ? plan.msplit : 1);
+}
+
+// Every workgroup of the cooperative launch resident at once.  Same-XCD hand-off (tile::kCoopSameXcd): blockIdx.x picks
+// the XCD (workgroups are dealt round-robin, gridDim.x is padded to a multiple of eight), so the members of
+// ceil(boards / 8) boards must fit ONE XCD's share of the CUs.
+bool coopFits(int boards, int members, int computeUnits) {
+    if (tile::kCoopSameXcd) return (long)((boards + 7) / 8) * members <= computeUnits / 8;
+    return (long)boards * members <= computeUnits;
 }
 
 hipError_t launchCoopTrunk(const void* devLayers, int nLayers, int batch, int cout, int prec, const ConvPlan& plan,

@@ -343,6 +343,7 @@ struct nsg_evaluator {
     int coopEnabled = 1;
     int coopForced = 0;         // NSG_COOP_TRUNK=1: wherever a plan allows it; unset: where it measured faster (enqueueForward)
     int lastPersistent = 0;     // what the most recent forward ran: 0 per-layer / persistent-without-hand-off, 1 team trunk, 2 cooperative trunk
+    int coopFaultXccLaunches = 0; // NSG_COOP_FAULT_XCC_LAUNCHES (test hook), see enqueueCoop
     int teamFaultLaunches = 0;  // NSG_TEAM_FAULT_LAUNCHES (test hook): this many team launches are made ONE WORKGROUP SHORT,
                                 // so that the team waits in vain, gives up and the recovery path runs
     // What the most recent compute call queued behind its forward: should the team launch of that forward give up
@@ -632,8 +633,11 @@ int enqueueCoop(nsg_evaluator* ev, int B, const nsg::ConvPlan& plan, hipStream_t
         const int l0 = stemFirst ? 1 : 0;
         if (trunkBegin) NSG_HIP(hipEventRecord(trunkBegin, s));
         // (test hook NSG_TEAM_FAULT_LAUNCHES: the last board's second member leaves at once and never publishes)
-        const int faultBoard = ev->teamFaultLaunches > 0 ? B - 1 : -1;
+        // (NSG_COOP_FAULT_XCC_LAUNCHES: every board's second member claims another XCD, what a placement the hand-off
+        // cannot use looks like)
+        int faultBoard = ev->teamFaultLaunches > 0 ? B - 1 : -1;
         if (faultBoard >= 0) --ev->teamFaultLaunches;
+        else if (ev->coopFaultXccLaunches > 0) { faultBoard = -2; --ev->coopFaultXccLaunches; }
         NSG_HIP(nsg::launchCoopTrunk((const unsigned char*)ev->trunkLayers.p + (size_t)l0 * nsg::trunkLayerBytes(),
                                      ev->trunkLayerCount - l0, B, ev->F, prec, plan, (unsigned*)ev->coopFlags.p,
                                      ev->teamStatusDev, s, faultBoard));
@@ -859,7 +863,7 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
     if (ev->coopEnabled && ev->teamStatusDev && ev->coopFlags.p && ev->tuning.nb == 0 && ev->tuning.nfrag == 0 &&
         ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && ev->useTrunkKernel != 1 && mx && ev->chainMinBatch <= 0 &&
         ev->chainDelayUs == 0 && nsg::canRunCoopTrunk(ev->F, ev->cpad, ev->prec, plan) &&
-        (long)B * nsg::coopMembers(ev->F, plan) <= ev->prop.multiProcessorCount &&
+        nsg::coopFits(B, nsg::coopMembers(ev->F, plan), ev->prop.multiProcessorCount) &&
         // measured (profiles/r04/o_cooperative_trunk_all_k_split_plans_sweep.txt): 256 channels with up to eight members
         // per board +1...8 % (24-128 boards), twelve members (17-21 boards) -3 %; 192 channels (13-us layers, three
         // members + row groups) -2...-8 % but for 85 boards: those keep their per-layer launches unless forced
@@ -1224,6 +1228,7 @@ static int checkTuningEnv() {
         {"NSG_COOP_TRUNK", 0, 1, "cooperative trunk for the two-way K split of the mid batches"},
         {"NSG_TEAM_MAX_BATCH", 0, 16, "largest batch that runs the team trunk"},
         {"NSG_TEAM_FAULT_LAUNCHES", 0, 1000000, "test hook: team launches made one workgroup short"},
+        {"NSG_COOP_FAULT_XCC_LAUNCHES", 0, 1000000, "test hook: cooperative launches whose members claim different XCDs"},
         {"NSG_TEAM_MEMBERS", 16, 96, "most workgroups per board of the team trunk on a 256-channel net: 16, 32, 48 or 96 "
                                      "(= 1, 2, 3 or 6 row groups; a 192-channel net runs 12 per row group)"}};
     for (const Var& v : vars) {
@@ -1297,6 +1302,7 @@ int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator**
     if (const char* e2 = getenv("NSG_CHAIN_MIN_BATCH")) ev->chainMinBatch = std::max(2, atoi(e2));
     if (const char* e2 = getenv("NSG_TEAM_MEMBERS")) ev->teamForceRowGroups = atoi(e2) / 16; // (validated above)
     if (const char* e2 = getenv("NSG_TEAM_FAULT_LAUNCHES")) ev->teamFaultLaunches = std::max(0, atoi(e2));
+    if (const char* e2 = getenv("NSG_COOP_FAULT_XCC_LAUNCHES")) ev->coopFaultXccLaunches = std::max(0, atoi(e2));
     if (const char* e2 = getenv("NSG_TEAM_MAX_BATCH")) ev->teamMaxBatch = std::min(std::max(0, atoi(e2)), (int)nsg::kTeamMaxBoards);
     *out = ev.release();
     return NSG_OK;
@@ -1881,7 +1887,15 @@ int nsg_get_info(nsg_evaluator* ev, nsg_info* info) {
 // epilogue done (s_memtime), -, -, s_memrealtime at epilogue done / at entry.
 int nsg_debug_stamps_enable(nsg_evaluator* ev) {
     if (!ev || !ev->loaded) return fail(NSG_E_INVALID, "load first");
-    return ev->stamps.alloc((size_t)2 * ev->blocks * 4096 * 8 * 8, true);
+    if (int rc = ev->stamps.alloc((size_t)2 * ev->blocks * 4096 * 8 * 8, true)) return rc;
+    // the persistent launches (trunk kernel, cooperative trunk) take their layers from the device list: layer l > 0 stamps
+    // where the per-layer launch of that convolution would
+    for (int l = 1; l < ev->trunkLayerCount; ++l) {
+        unsigned long long* st = (unsigned long long*)ev->stamps.p + (size_t)(l - 1) * 4096 * 8;
+        NSG_HIP(hipMemcpy((unsigned char*)ev->trunkLayers.p + (size_t)l * nsg::trunkLayerBytes() + nsg::trunkLayerStampsOffset(), &st,
+                          sizeof(st), hipMemcpyHostToDevice));
+    }
+    return NSG_OK;
 }
 int nsg_debug_stamps_read(nsg_evaluator* ev, unsigned long long* dst) {
     if (!ev || !ev->stamps.p) return fail(NSG_E_INVALID, "stamps not enabled");

@@ -1163,11 +1163,16 @@ def test_cooperative_trunk_mid_batches(nsg, oracle, monkeypatch, channels, batch
     auto, _ = make(nsg, 3, channels, batch, precision="f16m6", seed=610)
     auto.compute_blocking(nsg.synth.random_batch(batch, 86, seed=611, garbage=True))
     members = {2: 2, 3: 3, 4: 4}[ks] * auto.last_plan()["row_split"]
-    assert auto.last_launch_kind()[0] == ("coop" if channels == 256 and members <= 8 else "per_layer"), (auto.last_launch_kind(), members)
+    # the members of a board share an XCD (blockIdx.x picks it): ceil(batch / 8) boards' members must fit an XCD's CUs
+    fits = (batch + 7) // 8 * members <= cus // 8
+    assert auto.last_launch_kind()[0] == ("coop" if channels == 256 and members <= 8 and fits else "per_layer"), (auto.last_launch_kind(), members)
     monkeypatch.setenv("NSG_COOP_TRUNK", "1")  # ... here: every plan that has a cooperative form
     ev, blob = make(nsg, 3, channels, batch, precision="f16m6", seed=610)
     bb = nsg.synth.random_batch(batch, 86, seed=611, garbage=True)
     p, v, d = ev.compute_blocking(bb)
+    if not fits:
+        assert ev.last_launch_kind()[0] == "per_layer"
+        return
     assert ev.last_launch_kind() == ("coop", 1) and ev.last_plan()["k_split"] == ks, (ev.last_launch_kind(), ev.last_plan())
     assert ev.team_stats()["fallbacks"] == 0
     idx = sorted({0, batch // 2, batch - 1})
@@ -1207,4 +1212,28 @@ def test_cooperative_trunk_gives_up_and_the_batch_is_rerun(nsg, oracle, monkeypa
     check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
     p2, v2, d2 = ev.compute_blocking(bb)
     np.testing.assert_array_equal(p2, p)
+    assert ev.team_stats()["fallbacks"] == 1 and ev.stats()["batches"] == 2
+
+
+def test_cooperative_trunk_members_on_different_xcds_are_noticed(nsg, oracle, monkeypatch):
+    """The cooperative trunk hands a board's rows from member to member through the L2 of ONE XCD (plain stores,
+    L1-bypassing loads): every member publishes its XCC_ID with its flag and every poll compares it with the poller's own.
+    A member that reports another XCD (test hook) -- a placement the hand-off cannot use -- makes its board give up; the
+    waiting call re-runs the batch on the per-layer kernels, bit-identical, and later batches keep to them."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    batch = max(2, cus // 4 - 3)
+    ok, blob = make(nsg, 2, 256, batch, precision="f16m6", seed=630)
+    bb = nsg.synth.random_batch(batch, 86, seed=631)
+    p0, v0, d0 = ok.compute_blocking(bb)
+    assert ok.last_launch_kind()[0] == "coop" and ok.team_stats()["fallbacks"] == 0  # this GPU deals the members as assumed
+    monkeypatch.setenv("NSG_COOP_FAULT_XCC_LAUNCHES", "1")
+    ev, _ = make(nsg, 2, 256, batch, precision="f16m6", seed=630)
+    p, v, d = ev.compute_blocking(bb)
+    assert ev.team_stats()["fallbacks"] == 1 and ev.last_launch_kind() == ("per_layer", 0)
+    np.testing.assert_array_equal(p, p0)
+    np.testing.assert_array_equal(v, v0)
+    p2, v2, d2 = ev.compute_blocking(bb)
+    np.testing.assert_array_equal(p2, p0)
     assert ev.team_stats()["fallbacks"] == 1 and ev.stats()["batches"] == 2
