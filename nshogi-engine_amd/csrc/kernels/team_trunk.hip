@@ -73,6 +73,11 @@ constexpr int kEntries = 134;             // 24 + 110: one board with its halo (
 // same entries) then fall on disjoint banks -- with 134 * 16 = 2144 B planes every read cost 12 LDS cycles instead of
 // 4 and the eight waves' 54 reads per layer, not their 81 MFMAs, set the layer's compute time (5.0k of 15.6k cycles)
 constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
+// piece p of an image starts (p & 3) * kSkew bytes into its plane: a staging store writes, per group of eight lanes,
+// the four pieces of two neighbouring rows (the lane order that makes the global load of a row's pieces one line per
+// lane quad) -- same entry, four planes a multiple of 128 bytes apart, would be a 4-way bank conflict on every store
+constexpr int kSkew = 32;
+static_assert(kEntries * 16 + 3 * kSkew <= kPlane, "the skewed pieces must fit their planes");
 constexpr int kImage = 8 * kPlane;        // a wave's chunk: pieces 0-3 f16 hi, 4-7 f16 lo
 constexpr int kFlagOff = kWaves * kImage; // one int behind the images: raised by a wave whose bounded wait ran out
 constexpr int kLds = kFlagOff + 16;       // 147 472 B: the K parts' accumulators alias the images' interior entries
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 #pragma unroll
     for (int f = 0; f < FR; ++f) {
         const int m = (h * FR + f) * 16 + li;
-        abase[f] = ((m < 81 ? entryOf(m) : 11) - 11) * 16; // 11: every tap reads the zero entries
+        abase[f] = ((m < 81 ? entryOf(m) : 11) - 11) * 16 + g * kSkew; // 11: every tap reads the zero entries; pieces g and 4 + g
     }
     // staging.  Only the board rows this member's fragments and their 3x3 neighbours touch are fetched: squares 0..57
     // for the first row half of a 32-member team (fragments 0-2 = squares 0..47, + their neighbours below), 38..80
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 #pragma unroll
     for (int f = 0; f < FR; ++f) {
         const int slot = f * 64 + lane; // FR * 64 slots over the eight pieces: 8 * FR squares of each
-        redOff[f] = (slot / (8 * FR)) * kPlane + entryOf(slot % (8 * FR)) * 16;
+        redOff[f] = (slot / (8 * FR)) * kPlane + ((slot / (8 * FR)) & 3) * kSkew + entryOf(slot % (8 * FR)) * 16;
     }
     // output: lane (li, g) of fragment f holds channels ch0 .. ch0+3 of row (h*3+f)*16 + li
     const int ch0 = (j >> 2) * 64 + g * 16 + (j & 3) * 4;
@@ -189,11 +194,14 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
     // evaluator's layout (write-through: a store is paid per segment; profiles/r03/README.md).
     const int imgOff = (2 * (j >> 2) + (g >> 1)) * 128 + (j & 3) * 32 + (g & 1) * 16;
     // staging from an image: a lane takes BOTH pieces (members jq = 2 jp, 2 jp + 1; 32 bytes apart) of group gq of
-    // row 16 k + lane % 16: channels 16 gq + 8 jp .. + 7 of the chunk = LDS piece 2 gq + jp whole (hi; + 4 lo), one
-    // 16-byte LDS write each; 16 consecutive lanes write 16 consecutive rows of one piece: distinct banks.
-    const int stGq = (lane >> 4) & 1, stJp = lane >> 5;
+    // row 16 k + lane / 4: channels 16 gq + 8 jp .. + 7 of the chunk = LDS piece 2 gq + jp whole (hi; + 4 lo), one
+    // 16-byte LDS write each.  The four lanes of a QUAD take the four (gq, jp) of ONE row: each of their two loads
+    // touches one 128-byte line (with the row in lane % 16 a quad read four rows, four lines, and the texture unit
+    // took ~3x as long per wave load: mfma_tile.h, staging); eight consecutive lanes write two rows x four pieces,
+    // on eight different 16-byte slots thanks to the pieces' skew.
+    const int stGq = lane & 1, stJp = (lane >> 1) & 1, sli = lane >> 2;
     const int imgSrc = (2 * stJp) * 32 + stGq * 16; // inside the wave's chunk of a row
-    const int imgDst = (2 * stGq + stJp) * kPlane;
+    const int imgDst = (2 * stGq + stJp) * (kPlane + kSkew);
     // items (16 rows each) a member stages: the rows of its fragments and one board row either side = at most FR + 2
     // consecutive items from item h * FR - 1 on
     constexpr int kImgItems = FR + 2 < 6 ? FR + 2 : 6;
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                             : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < kImgItems; ++k) {
-                const int row = (item0 + k) * 16 + li;
+                const int row = (item0 + k) * 16 + sli;
                 if (row < rowLo || row > rowHi) continue;
                 unsigned hi[4], lo[4];
 #pragma unroll
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
             unsigned pend = 0;
 #pragma unroll
             for (int k = 0; k < kImgItems; ++k) {
-                const int row = (item0 + k) * 16 + li;
+                const int row = (item0 + k) * 16 + sli;
                 if (row >= rowLo && row <= rowHi) pend |= 1u << k;
             }
             auto request = [&] {
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
 #pragma unroll
                 for (int k = 0; k < kImgItems; ++k)
                     if ((pend >> k) & 1u) {
-                        const int src = xb + ((item0 + k) * 16 + li) * (int)inRow;
+                        const int src = xb + ((item0 + k) * 16 + sli) * (int)inRow;
                         st[2 * k] = loadAgent16(xBuf, src);
                         st[2 * k + 1] = loadAgent16(xBuf, src + second);
                     }
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(kThreads, 2) void teamTrunkKernel(const TeamLayer* 
                     // (no word of a stored piece is all ones: the largest of the eight tells)
                     const unsigned top = umax3(umax3(a.x, a.y, a.z), umax3(a.w, b.x, b.y), b.z > b.w ? b.z : b.w);
                     if (top != 0xffffffffu) {
-                        unsigned char* d = img + imgDst + entry16((item0 + k) * 16 + li);
+                        unsigned char* d = img + imgDst + entry16((item0 + k) * 16 + sli);
                         *reinterpret_cast<u32x4*>(d) = fromImage ? u32x4{a.x, a.y, b.x, b.y} : a;
                         *reinterpret_cast<u32x4*>(d + 4 * kPlane) = fromImage ? u32x4{a.z, a.w, b.z, b.w} : b;
                         pend &= ~(1u << k);
