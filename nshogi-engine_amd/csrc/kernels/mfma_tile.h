@@ -82,14 +82,14 @@ struct Geom {
     static constexpr int kRows = kBoards ? SIZE * 81 : SIZE * 16;
     static constexpr int kMF = (kRows + 15) / 16;
     static constexpr int kEntries = kBoards ? SIZE * 110 + 24 : kMF * 16;
-    static constexpr int kPlane = (kEntries * 16 + 255) / 256 * 256;
-    // Plane p of a chunk buffer starts (p & 3) * kSkew bytes into its slot.  A staging store writes, per group of
-    // eight lanes, the four 16-byte pieces of two neighbouring rows (the lane order that makes the global load of those
-    // pieces one 64-byte segment per lane quad): without the skew the four pieces of a row -- same entry, four planes,
-    // planes a multiple of 128 bytes apart -- fall on the same banks (4-way conflict on every ds_write_b128); skewed by
-    // 32 bytes each, the eight pieces of a group cover eight different 16-byte slots.
-    static constexpr int kSkew = kBoards ? 32 : 0;
-    static_assert(kEntries * 16 + 3 * kSkew <= kPlane, "the skewed planes must fit their slots");
+    // Plane p of a chunk buffer starts at p * kPlaneStride = p * (kPlane + 16): one 16-byte slot further on in the banks
+    // than the plane before.  A staging store writes, per group of eight lanes, the eight pieces of ONE row (the lane
+    // order that makes the global load of a row's 128-byte chunk one cache line per eight lanes): same entry, eight
+    // planes -- a multiple of 128 bytes apart they would all fall on the same banks (8-way conflict on every
+    // ds_write_b128); one slot apart they cover eight different slots.
+    static constexpr int kPlane = (kEntries * 16 + 7 * 16 + 255) / 256 * 256;
+    static constexpr int kPlaneStride = kPlane + 16;
+    static_assert(7 * kPlaneStride + kEntries * 16 <= 8 * kPlane, "the eight skewed planes must fit the buffer");
     static constexpr int kBuf = 8 * kPlane;  // one 128-byte channel chunk
     static constexpr int kLds = NBUF * kBuf; // double buffered (kF16m8: four buffers = two chunk pairs)
     // LDS the epilogue may stage through: a two-board tile has the CU to itself (its waves need the
@@ -118,7 +118,7 @@ __device__ __forceinline__ int entryOfRow(int m) {
 }
 
 // Zeroes the HALO entries of every image plane: the 24 leading entries, per board the rows y = -1 and
-// y = 9 and the column x = 9, and the padding behind the last board.  The interior entries are rewritten
+// y = 9 and the column x = 9 (nothing reads past the last board's image).  The interior entries are rewritten
 // by the staging of every chunk before anything reads them, so clearing the whole image (36 16-byte
 // stores per thread for the eight resident buffers of a K-split tile, 2.8k of its 9.7k prologue cycles)
 // is 2-3x the work needed.  Lane l owns halo entry l (+64, ...) and walks the planes: one address
@@ -129,8 +129,7 @@ template <class G, bool SHIFT = false>
 __device__ __forceinline__ void zeroHalo(unsigned char* smem, int tid) {
     static_assert(G::kBoards, "board images only");
     constexpr int kBoardsN = (G::kEntries - 24) / 110;
-    constexpr int kPlaneEntries = G::kPlane / 16;
-    constexpr int kHalo = 24 + 29 * kBoardsN + (kPlaneEntries - G::kEntries);
+    constexpr int kHalo = 24 + 29 * kBoardsN;
     constexpr int kPlanes = G::kLds / G::kPlane;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int kWavesN = G::kThreads / 64;
@@ -145,8 +144,7 @@ __device__ __forceinline__ void zeroHalo(unsigned char* smem, int tid) {
         if (h0 + 63 >= 24) {
             const int q = h - 24, b = q / 29, r = q - b * 29;
             const int within = r < 10 ? r : (r < 19 ? (r - 9) * 10 + 9 : 81 + r); // y = -1 | x = 9 of y = 0..8 | y = 9
-            const int eb = b < kBoardsN ? 24 + b * 110 + within : G::kEntries + (q - 29 * kBoardsN);
-            e = h < 24 ? h : eb;
+            e = h < 24 ? h : 24 + b * 110 + within;
         }
         e = h < kHalo ? e : 0;
 #pragma unroll
@@ -154,11 +152,11 @@ __device__ __forceinline__ void zeroHalo(unsigned char* smem, int tid) {
             int plane = pl * kWavesN + wave;
             plane = plane < kPlanes ? plane : kPlanes - 1;
             if constexpr (SHIFT) {
-                unsigned char* z = smem + e * 16 + (size_t)plane * G::kPlane + (plane & 3) * G::kSkew + ((plane & 7) == 7 ? 8 : 0);
+                unsigned char* z = smem + e * 16 + (plane >> 3) * G::kBuf + (plane & 7) * G::kPlaneStride + ((plane & 7) == 7 ? 8 : 0);
                 *reinterpret_cast<u32x2*>(z) = u32x2{0u, 0u};
                 *reinterpret_cast<u32x2*>(z + 8) = u32x2{0u, 0u};
             } else {
-                *reinterpret_cast<u32x4*>(smem + e * 16 + (size_t)plane * G::kPlane + (plane & 3) * G::kSkew) = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(smem + e * 16 + (plane >> 3) * G::kBuf + (plane & 7) * G::kPlaneStride) = u32x4{0u, 0u, 0u, 0u};
             }
         }
     }
@@ -551,23 +549,24 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     // kConv buffers are sized for whole workgroups; flat modes clamp rows.
     const size_t lastRow = G::kBoards ? ~(size_t)0 : (size_t)(A.totalRows - 1);
 
-    // staging: item k of this wave moves 16 rows x 4 pieces (16 B per lane) = one 64-byte half of a channel chunk per row.
-    // Lane order of the move: piece = lane & 3, row = lane >> 2 -- a lane QUAD reads one contiguous 64-byte segment.
-    // (In the MFMA operand order -- row = lane & 15, piece = lane >> 4 -- every quad read four different rows, four
-    // cache lines: the texture unit took ~47 cycles per 1-KiB wave load instead of 16, and the 24 tile loads a wave of
-    // a K-split tile issues at the top of every layer took 4.5k cycles to ISSUE: profiles/r04/w_*, y_*.)
-    const int sli = lane >> 2, sg = lane & 3;
+    // staging: item k of this wave moves 8 rows x 8 pieces (16 B per lane) = the whole 128-byte channel chunk of a row.
+    // Lane order of the move: piece = lane & 7, row = lane >> 3 -- eight consecutive lanes read one cache line.
+    // (In the MFMA operand order -- row = lane & 15, piece = lane >> 4, an item = 16 rows x half a chunk -- every lane
+    // quad read four different rows, four cache lines, each line was requested twice, by different instructions, and
+    // the texture unit took ~47 cycles per 1-KiB wave load instead of 16: the 24 tile loads a wave of a K-split tile
+    // issues at the top of every layer took 4.5k cycles to ISSUE; profiles/r04/w_*, y_*, zb_*.)
+    const int sli = lane >> 3, sg = lane & 7;
     size_t srcOff[G::kItems];
     int dstOff[G::kItems];
     bool itemOk[G::kItems];
 #pragma unroll
     for (int k = 0; k < G::kItems; ++k) {
         const int wid = wave + k * NWAVES;
-        const int m = (wid >> 1) * 16 + sli;
+        const int m = wid * 8 + sli;
         itemOk[k] = (wid < 2 * G::kMF) && (m < G::kRows);
         size_t grow = row0 + (itemOk[k] ? m : 0);
         if (grow > lastRow) grow = lastRow;
-        srcOff[k] = grow * (size_t)A.kdim * ES + ((wid & 1) * 4 + sg) * 16 + (size_t)kc0 * 128;
+        srcOff[k] = grow * (size_t)A.kdim * ES + sg * 16 + (size_t)kc0 * 128;
     }
     // MX conv tiles read their input through a buffer descriptor on the workgroup's own boards: a 32-bit lane offset
     // inside the tile + a wave-uniform chunk offset, instead of a 64-bit address per item (the loop has no vector
@@ -626,13 +625,13 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #pragma unroll
     for (int k = 0; k < G::kItems; ++k) {
         const int wid = wave + k * NWAVES;
-        const int c = (wid & 1) * 4 + sg;
-        const int mm = itemOk[k] ? (wid >> 1) * 16 + sli : 0;
+        const int c = sg;
+        const int mm = itemOk[k] ? wid * 8 + sli : 0;
         // masked lanes store to their own trash slot behind both buffers (one shared slot made
         // every masked store a 64-way same-address conflict that stalled the whole LDS): the store
         // stays unconditional, so st[] stays in registers
         // (bit select, not ?: -- the compiler turned the conditional into a far out-of-line block per item)
-        const int okOff = c * G::kPlane + sg * G::kSkew + entryOfRow<G::kBoards>(mm) * 16 + ((kShiftLo && c == 7) ? 8 : 0), okMask = -(int)itemOk[k];
+        const int okOff = c * G::kPlaneStride + entryOfRow<G::kBoards>(mm) * 16 + ((kShiftLo && c == 7) ? 8 : 0), okMask = -(int)itemOk[k];
         dstOff[k] = (okOff & okMask) | ((G::kLds + lane * 16) & ~okMask);
     }
 
@@ -661,9 +660,9 @@ _Pragma("unroll") \
         if constexpr (G::kBoards) { \
             const int p = kPerm ? (eok ? 24 + eb * 110 + (ey + 1) * 10 + ex : 11) \
                                 : ((m < G::kRows) ? entryOfRow<true>(m) : 11); \
-            abase[f] = g * (G::kPlane + G::kSkew) + (p - 11) * 16; \
+            abase[f] = g * G::kPlaneStride + (p - 11) * 16; \
         } else { \
-            abase[f] = g * (G::kPlane + G::kSkew) + m * 16; \
+            abase[f] = g * G::kPlaneStride + m * 16; \
         } \
     }
     if constexpr (!kPerm) { NSG_COMPUTE_ABASE }
@@ -736,8 +735,8 @@ _Pragma("unroll") \
         static_assert(kWriteStepB < kBarStep, "tile staging order");
         auto tapOff = [](int t) constexpr { return ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16; };
         // MX operand of lane (li, g): 32 fp8 bytes of chunk g>>1 (A / B buffer); g&1 ? lo bytes : hi bytes
-        // (planes 4 + 2 * (g & 1) and the one behind it; abase holds plane g and its skew)
-        const int offp8 = (g >> 1) * G::kBuf + (4 + 2 * (g & 1) - g) * G::kPlane + (2 * (g & 1) - g) * G::kSkew;
+        // (planes 4 + 2 * (g & 1) and the one behind it; abase holds plane g)
+        const int offp8 = (g >> 1) * G::kBuf + (4 + 2 * (g & 1) - g) * G::kPlaneStride;
         // Weight records of a chunk pair, per tap: [main A: nft KiB][main B: nft KiB][MX slab].  kF16m8: the MX slab is
         // two 1-KiB records per fragment (32 fp8 bytes per lane).  kF16m6 (kPackX): per group of four fragments
         // [4 x 1 KiB: code dwords 0-3][4 x 512 B: code dwords 4-5][256 B: one dword per lane = the four fragments'
@@ -843,7 +842,7 @@ _Pragma("unroll") \
         // instruction per MX step does not.  What the loop is short of is LDS issue, not vector issue.
         constexpr bool kSplitRead = kShiftLo && OS::kX > 0;
         // (without the split read, plane 7's shift still applies: its piece is read at + 8)
-        const int offB = offp8 + G::kPlane + G::kSkew + 8 * (g & 1);
+        const int offB = offp8 + G::kPlaneStride + 8 * (g & 1);
         u32x4 aw[kWin][kSplitRead ? 1 : 2];
         [[maybe_unused]] u32x2 aw45[kSplitRead ? kWin : 1];
         [[maybe_unused]] uint32_t awS[kSplitRead ? kWin : 1];
@@ -863,7 +862,7 @@ _Pragma("unroll") \
                 } else if constexpr (kShiftLo) {                                                  \
                     aw[(QQ) % kWin][kSplitRead ? 0 : 1] = *reinterpret_cast<const u32x4*>(ap2_);  \
                 } else {                                                                          \
-                    aw[(QQ) % kWin][kSplitRead ? 0 : 1] = *reinterpret_cast<const u32x4*>(ap_ + G::kPlane + G::kSkew); \
+                    aw[(QQ) % kWin][kSplitRead ? 0 : 1] = *reinterpret_cast<const u32x4*>(ap_ + G::kPlaneStride); \
                 }                                                                                 \
             } else {                                                                              \
                 aw[(QQ) % kWin][0] = *reinterpret_cast<const u32x4*>(                             \
@@ -1088,7 +1087,7 @@ _Pragma("unroll") \
         const int t = s / kSlabsPerTap;
         const int r = s % kSlabsPerTap;
         const int piece = kSplit ? (r == 2 ? 4 : 0) : r * 4;
-        return (G::kBoards ? ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16 : 0) + piece * G::kPlane;
+        return (G::kBoards ? ((t / 3 - 1) * 10 + (t % 3 - 1) + 11) * 16 : 0) + piece * G::kPlaneStride;
     };
     // Ring depths: a slab of a full tile is 44 MFMAs (~700 cycles) and covers an L2
     // round trip with one slab of lead; a small-batch tile has as few as 6 MFMAs per
