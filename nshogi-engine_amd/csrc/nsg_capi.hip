@@ -864,10 +864,11 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && ev->useTrunkKernel != 1 && mx && ev->chainMinBatch <= 0 &&
         ev->chainDelayUs == 0 && nsg::canRunCoopTrunk(ev->F, ev->cpad, ev->prec, plan) &&
         nsg::coopFits(B, nsg::coopMembers(ev->F, plan), ev->prop.multiProcessorCount) &&
-        // measured (profiles/r04/o_cooperative_trunk_all_k_split_plans_sweep.txt): 256 channels with up to eight members
-        // per board +1...8 % (24-128 boards), twelve members (17-21 boards) -3 %; 192 channels (13-us layers, three
-        // members + row groups) -2...-8 % but for 85 boards: those keep their per-layer launches unless forced
-        (ev->coopForced || (ev->F == 256 && nsg::coopMembers(ev->F, plan) <= 8))) {
+        // measured: 256 channels with up to eight members per board +1...8 % (24-128 boards;
+        // profiles/r04/o_cooperative_trunk_all_k_split_plans_sweep.txt; twelve members, 17-21 boards, do not fit an
+        // XCD's CUs three boards at a time); 192 channels +1...9 % (17-80 boards) since the hand-off stays in the XCD's L2
+        // (profiles/r04/zd_cooperative_trunk_192_channels.txt; -2...-8 % with write-through stores)
+        (ev->coopForced || (ev->F == 256 && nsg::coopMembers(ev->F, plan) <= 8) || ev->F == 192)) {
         int rc;
         {
             TeamTokenGuard token(ev);
