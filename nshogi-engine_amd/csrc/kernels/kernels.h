@@ -138,7 +138,7 @@ bool coopFits(int boards, int members, int computeUnits); // every workgroup of 
 int coopMembers(int cout, const ConvPlan& plan); // workgroups per board
 // (faultBoard >= 0: test hook -- that board's second member leaves at once, so its first waits in vain)
 hipError_t launchCoopTrunk(const void* devLayers, int nLayers, int batch, int cout, int prec, const ConvPlan& plan,
-                           unsigned* flags, int* status, hipStream_t stream, int faultBoard = -1);
+                           unsigned* flags, unsigned flagBase, int* status, hipStream_t stream, int faultBoard);
 
 // Team trunk (team_trunk.hip): every 3x3 layer of up to sixteen boards in ONE persistent launch, a board per team of
 // 16 / 32 / 48 / 96 workgroups (12 / 24 / 36 / 72 for 192 trunk channels) that hand activations to each other through

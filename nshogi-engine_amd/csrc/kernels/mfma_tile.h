@@ -1856,7 +1856,9 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
 // mid batches: gridDim.y workgroups per board, each a 64- or 128-channel slice) in ONE launch.  A per-layer kernel ends
 // when its slowest workgroup does, 41 times per forward; here a workgroup waits only for the other workgroups OF ITS
 // BOARD: member m of board b publishes flag[b][m] = l + 1 behind its layer-l stores and polls its neighbours' flags
-// before layer l + 1.  The hand-off is MI355X_MICROARCH's measured form: every store of the payload sc1 (write-through),
+// before layer l + 1 (flag values count on from `flagBase`, which the host advances by more than a launch's layers from
+// launch to launch: what an earlier launch left in the array -- under any member count -- is below every value this one
+// waits for, and the array needs no clearing between launches).  The hand-off is MI355X_MICROARCH's measured form: every store of the payload sc1 (write-through),
 // every storing wave waits for its stores (vmcnt(0)), a workgroup barrier, ONE lane stores the flag (sc1); the consumer
 // polls with sc1 loads, a workgroup barrier, then reads the payload with sc1 loads only (tileBody, COOP).  The flag
 // of layer l also orders the write-after-read hazards of the three rotating activation buffers: a member can reach the
@@ -1876,7 +1878,7 @@ __global__ __launch_bounds__(NWAVES * 64, (minWavesPerSimd<kConv, SIZE, NWAVES, 
 // spin and the host re-runs the batch on the per-layer kernels and stops using this launch (nsg_capi.hip, teamRecover).
 template <int PREC, int NFRAG, int NWAVES, int MS, int KS>
 __global__ __launch_bounds__(NWAVES * 64, 1) void coopTrunkKernel(const Args* __restrict__ layers, int nLayers, int boards,
-                                                                  unsigned* flags, int* status, int faultBoard) {
+                                                                  unsigned* flags, unsigned flagBase, int* status, int faultBoard) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = Geom<kConv, 1, NWAVES, 8>;
     if ((int)blockIdx.x >= boards) return; // (gridDim.x is padded to a multiple of eight)
@@ -1901,7 +1903,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void coopTrunkKernel(const Args* __
             if ((int)threadIdx.x < members && (int)threadIdx.x != me) { // one polling lane per neighbour (wave 0)
                 int spins = 0;
                 unsigned seen;
-                while (((seen = __hip_atomic_load(mine + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < (unsigned)l) {
+                while (((seen = __hip_atomic_load(mine + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < flagBase + (unsigned)l) {
                     if ((++spins & 255) == 0 &&
                         (spins > (1 << 21) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
                         __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1923,13 +1925,13 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void coopTrunkKernel(const Args* __
         else tileBody<PREC, kConv, 1, NFRAG, NWAVES, 0, MS, KS, 1, 0, true>(A, smem, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its write-through stores have left
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(mine + me, (unsigned)(l + 1) | (xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(mine + me, (flagBase + (unsigned)(l + 1)) | (xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 template <int PREC, int NFRAG, int NWAVES, int MS, int KS>
-hipError_t launchCoopOne(const Args* layers, int nLayers, int boards, int cout, unsigned* flags, int* status, hipStream_t stream,
-                         int faultBoard) {
+hipError_t launchCoopOne(const Args* layers, int nLayers, int boards, int cout, unsigned* flags, unsigned flagBase, int* status,
+                         hipStream_t stream, int faultBoard) {
     using G = Geom<kConv, 1, NWAVES, 8>;
     constexpr bool kRowWG = (MS > 1 && KS > 1);
     constexpr int kChanGroups = NWAVES / (kRowWG ? KS : MS * KS);
@@ -1946,7 +1948,7 @@ hipError_t launchCoopOne(const Args* layers, int nLayers, int boards, int cout, 
     }
     // (gridDim.x padded to a multiple of eight: blockIdx.x picks the XCD, coopTrunkKernel)
     hipLaunchKernelGGL(k, dim3((boards + 7) / 8 * 8, gy, kRowWG ? MS : 1), dim3(G::kThreads), G::kLdsAlloc + 16, stream, layers, nLayers,
-                       boards, flags, status, faultBoard);
+                       boards, flags, flagBase, status, faultBoard);
     return hipGetLastError();
 }
 
@@ -2057,8 +2059,8 @@ hipError_t launchConvF16m8(const Args& a, int batch, const ConvPlan& p, hipStrea
 hipError_t launchTrunkF16m8(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchConvF16m6(const Args& a, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkF16m6(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
-hipError_t launchCoopTrunkF16m6(const Args* layers, int n, int batch, int cout, const ConvPlan& p, unsigned* flags, int* status,
-                                hipStream_t s, int faultBoard);
+hipError_t launchCoopTrunkF16m6(const Args* layers, int n, int batch, int cout, const ConvPlan& p, unsigned* flags, unsigned flagBase,
+                                int* status, hipStream_t s, int faultBoard);
 hipError_t launchTrunkFp32(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkFp16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);
 hipError_t launchTrunkBf16(const Args* layers, int n, int batch, const ConvPlan& p, hipStream_t s);

@@ -62,24 +62,24 @@ hipError_t launchTrunkF16m6(const Args* layers, int n, int batch, const ConvPlan
     return hipErrorInvalidValue;
 }
 
-hipError_t launchCoopTrunkF16m6(const Args* layers, int n, int batch, int cout, const ConvPlan& p, unsigned* flags, int* status,
-                                hipStream_t s, int faultBoard) {
+hipError_t launchCoopTrunkF16m6(const Args* layers, int n, int batch, int cout, const ConvPlan& p, unsigned* flags, unsigned flagBase,
+                                int* status, hipStream_t s, int faultBoard) {
     if (p.nb != 1 || p.nfrag != 4 || p.sslab != 1) return hipErrorInvalidValue;
     // the two-way K split of the mid batches: two workgroups per board (128 channels each) on 256 channels
-    if (p.nwaves == 4 && p.ksplit == 2 && p.msplit == 1) return launchCoopOne<kF16m6, 4, 4, 1, 2>(layers, n, batch, cout, flags, status, s, faultBoard);
+    if (p.nwaves == 4 && p.ksplit == 2 && p.msplit == 1) return launchCoopOne<kF16m6, 4, 4, 1, 2>(layers, n, batch, cout, flags, flagBase, status, s, faultBoard);
     // the four-way K split of the small batches: four workgroups per board x 1 / 2 / 3 / 6 row groups
     if (p.nwaves == 4 && p.ksplit == 4) {
-        if (p.msplit == 1) return launchCoopOne<kF16m6, 4, 4, 1, 4>(layers, n, batch, cout, flags, status, s, faultBoard);
-        if (p.msplit == 2) return launchCoopOne<kF16m6, 4, 4, 2, 4>(layers, n, batch, cout, flags, status, s, faultBoard);
-        if (p.msplit == 3) return launchCoopOne<kF16m6, 4, 4, 3, 4>(layers, n, batch, cout, flags, status, s, faultBoard);
-        if (p.msplit == 6) return launchCoopOne<kF16m6, 4, 4, 6, 4>(layers, n, batch, cout, flags, status, s, faultBoard);
+        if (p.msplit == 1) return launchCoopOne<kF16m6, 4, 4, 1, 4>(layers, n, batch, cout, flags, flagBase, status, s, faultBoard);
+        if (p.msplit == 2) return launchCoopOne<kF16m6, 4, 4, 2, 4>(layers, n, batch, cout, flags, flagBase, status, s, faultBoard);
+        if (p.msplit == 3) return launchCoopOne<kF16m6, 4, 4, 3, 4>(layers, n, batch, cout, flags, flagBase, status, s, faultBoard);
+        if (p.msplit == 6) return launchCoopOne<kF16m6, 4, 4, 6, 4>(layers, n, batch, cout, flags, flagBase, status, s, faultBoard);
     }
     // 192 channels: the three-way K split, three workgroups per board x row groups
     if (p.nwaves == 3 && p.ksplit == 3) {
-        if (p.msplit == 1) return launchCoopOne<kF16m6, 4, 3, 1, 3>(layers, n, batch, cout, flags, status, s, faultBoard);
-        if (p.msplit == 2) return launchCoopOne<kF16m6, 4, 3, 2, 3>(layers, n, batch, cout, flags, status, s, faultBoard);
-        if (p.msplit == 3) return launchCoopOne<kF16m6, 4, 3, 3, 3>(layers, n, batch, cout, flags, status, s, faultBoard);
-        if (p.msplit == 6) return launchCoopOne<kF16m6, 4, 3, 6, 3>(layers, n, batch, cout, flags, status, s, faultBoard);
+        if (p.msplit == 1) return launchCoopOne<kF16m6, 4, 3, 1, 3>(layers, n, batch, cout, flags, flagBase, status, s, faultBoard);
+        if (p.msplit == 2) return launchCoopOne<kF16m6, 4, 3, 2, 3>(layers, n, batch, cout, flags, flagBase, status, s, faultBoard);
+        if (p.msplit == 3) return launchCoopOne<kF16m6, 4, 3, 3, 3>(layers, n, batch, cout, flags, flagBase, status, s, faultBoard);
+        if (p.msplit == 6) return launchCoopOne<kF16m6, 4, 3, 6, 3>(layers, n, batch, cout, flags, flagBase, status, s, faultBoard);
     }
     return hipErrorInvalidValue;
 }

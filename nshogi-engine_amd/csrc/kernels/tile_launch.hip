@@ -182,9 +182,10 @@ bool coopFits(int boards, int members, int computeUnits) {
 }
 
 hipError_t launchCoopTrunk(const void* devLayers, int nLayers, int batch, int cout, int prec, const ConvPlan& plan,
-                           unsigned* flags, int* status, hipStream_t stream, int faultBoard) {
-    if (batch <= 0 || nLayers <= 0 || !flags || !status || prec != kF16m6) return hipErrorInvalidValue;
-    return tile::launchCoopTrunkF16m6((const tile::Args*)devLayers, nLayers, batch, cout, plan, flags, status, stream, faultBoard);
+                           unsigned* flags, unsigned flagBase, int* status, hipStream_t stream, int faultBoard) {
+    if (batch <= 0 || nLayers <= 0 || !flags || !status || prec != kF16m6 || flagBase + (unsigned)nLayers + 1 >= (1u << 24))
+        return hipErrorInvalidValue;
+    return tile::launchCoopTrunkF16m6((const tile::Args*)devLayers, nLayers, batch, cout, plan, flags, flagBase, status, stream, faultBoard);
 }
 
 hipError_t launchHeads(const void* x, const void* wfrag, const float* bias,

@@ -339,7 +339,8 @@ struct nsg_evaluator {
     // Cooperative trunk (mfma_tile.h, coopTrunkKernel): the two-way K split of 65 ... CUs/2 boards as ONE launch whose
     // two workgroups per board hand their halves to each other.  NSG_COOP_TRUNK=0 switches it off.  Shares the team
     // trunk's device token (both need every workgroup of their grid resident), status word and recovery.
-    DevBuf coopFlags;           // [batchMax][members] unsigned, zeroed before every launch
+    DevBuf coopFlags;           // [batchMax][members] unsigned; values count on from launch to launch (coopFlagBase)
+    unsigned coopFlagBase = 0;  // first flag value of the next cooperative launch
     int coopEnabled = 1;
     int coopForced = 0;         // NSG_COOP_TRUNK=1: wherever a plan allows it; unset: where it measured faster (enqueueForward)
     int lastPersistent = 0;     // what the most recent forward ran: 0 per-layer / persistent-without-hand-off, 1 team trunk, 2 cooperative trunk
@@ -626,7 +627,14 @@ int enqueueCoop(nsg_evaluator* ev, int B, const nsg::ConvPlan& plan, hipStream_t
         const int members = nsg::coopMembers(ev->F, plan);
         bool stemFirst = false;
         (void)nsg::canRunCoopTrunk(ev->F, ev->cpad, prec, plan, &stemFirst);
-        NSG_HIP(hipMemsetAsync(ev->coopFlags.p, 0, (size_t)B * members * sizeof(unsigned), s));
+        // flag values count on across launches (24 bits; the array is cleared when they run out): no memset per forward
+        if (ev->coopFlagBase + 256u >= (1u << 24)) {
+            NSG_HIP(hipMemsetAsync(ev->coopFlags.p, 0, ev->coopFlags.bytes, s));
+            ev->coopFlagBase = 0;
+        }
+        const unsigned flagBase = ev->coopFlagBase;
+        ev->coopFlagBase += 128; // (more than any net's 3x3 layers: 1 + 2 x 40)
+        (void)members;
         if (stemFirst) // the stem has fewer chunk pairs than the plan splits K by: its own launch, the plan's stem kernel
             NSG_HIP(nsg::launchConv3x3(ev->planes.p, ev->W->stem.w.p, (const float*)ev->W->stem.bias.p, nullptr, ev->act[0].p, B,
                                        ev->cpad, ev->F, 1, ev->W->stem.accScale, prec, plan, s, nullptr, false));
@@ -639,7 +647,7 @@ int enqueueCoop(nsg_evaluator* ev, int B, const nsg::ConvPlan& plan, hipStream_t
         if (faultBoard >= 0) --ev->teamFaultLaunches;
         else if (ev->coopFaultXccLaunches > 0) { faultBoard = -2; --ev->coopFaultXccLaunches; }
         NSG_HIP(nsg::launchCoopTrunk((const unsigned char*)ev->trunkLayers.p + (size_t)l0 * nsg::trunkLayerBytes(),
-                                     ev->trunkLayerCount - l0, B, ev->F, prec, plan, (unsigned*)ev->coopFlags.p,
+                                     ev->trunkLayerCount - l0, B, ev->F, prec, plan, (unsigned*)ev->coopFlags.p, flagBase,
                                      ev->teamStatusDev, s, faultBoard));
         NSG_HIP(hipEventRecord(ev->teamDone, s));
         if (trunkEnd) NSG_HIP(hipEventRecord(trunkEnd, s));
@@ -864,6 +872,7 @@ int enqueueForward(nsg_evaluator* ev, size_t n) {
         ev->tuning.nwaves == 0 && ev->tuning.msplit == 0 && ev->useTrunkKernel != 1 && mx && ev->chainMinBatch <= 0 &&
         ev->chainDelayUs == 0 && nsg::canRunCoopTrunk(ev->F, ev->cpad, ev->prec, plan) &&
         nsg::coopFits(B, nsg::coopMembers(ev->F, plan), ev->prop.multiProcessorCount) &&
+        ev->trunkLayerCount < 127 && // (a launch's flag values fit the 128 the base advances by)
         // measured: 256 channels with up to eight members per board +1...8 % (24-128 boards;
         // profiles/r04/o_cooperative_trunk_all_k_split_plans_sweep.txt; twelve members, 17-21 boards, do not fit an
         // XCD's CUs three boards at a time); 192 channels +1...9 % (17-80 boards) since the hand-off stays in the XCD's L2
@@ -1230,6 +1239,7 @@ static int checkTuningEnv() {
         {"NSG_TEAM_MAX_BATCH", 0, 16, "largest batch that runs the team trunk"},
         {"NSG_TEAM_FAULT_LAUNCHES", 0, 1000000, "test hook: team launches made one workgroup short"},
         {"NSG_COOP_FAULT_XCC_LAUNCHES", 0, 1000000, "test hook: cooperative launches whose members claim different XCDs"},
+        {"NSG_COOP_FLAG_BASE", 0, (1 << 24) - 1, "test hook: first flag value of the evaluator's first cooperative launch"},
         {"NSG_TEAM_MEMBERS", 16, 96, "most workgroups per board of the team trunk on a 256-channel net: 16, 32, 48 or 96 "
                                      "(= 1, 2, 3 or 6 row groups; a 192-channel net runs 12 per row group)"}};
     for (const Var& v : vars) {
@@ -1304,6 +1314,7 @@ int nsg_create(int gpu_id, int batch_size_max, int num_channels, nsg_evaluator**
     if (const char* e2 = getenv("NSG_TEAM_MEMBERS")) ev->teamForceRowGroups = atoi(e2) / 16; // (validated above)
     if (const char* e2 = getenv("NSG_TEAM_FAULT_LAUNCHES")) ev->teamFaultLaunches = std::max(0, atoi(e2));
     if (const char* e2 = getenv("NSG_COOP_FAULT_XCC_LAUNCHES")) ev->coopFaultXccLaunches = std::max(0, atoi(e2));
+    if (const char* e2 = getenv("NSG_COOP_FLAG_BASE")) ev->coopFlagBase = (unsigned)std::max(0, atoi(e2));
     if (const char* e2 = getenv("NSG_TEAM_MAX_BATCH")) ev->teamMaxBatch = std::min(std::max(0, atoi(e2)), (int)nsg::kTeamMaxBoards);
     *out = ev.release();
     return NSG_OK;

@@ -1215,6 +1215,30 @@ def test_cooperative_trunk_gives_up_and_the_batch_is_rerun(nsg, oracle, monkeypa
     assert ev.team_stats()["fallbacks"] == 1 and ev.stats()["batches"] == 2
 
 
+def test_cooperative_trunk_flag_values_run_out_and_start_again(nsg, monkeypatch):
+    """The cooperative trunk's flags are not cleared between launches: their values count on from launch to launch (24
+    bits under the XCC_ID byte) and the array is cleared when they run out.  Launches on either side of that point, and a
+    launch with another member count in between, give the per-layer kernels' outputs."""
+    probe = nsg.Evaluator(0, 1, 86)
+    cus = probe.info()["compute_units"]
+    del probe
+    big, small = max(2, cus // 2 - 9), max(2, cus // 8)
+    monkeypatch.setenv("NSG_COOP_TRUNK", "0")
+    per, blob = make(nsg, 2, 256, big, precision="f16m6", seed=640)
+    bb = nsg.synth.random_batch(big, 86, seed=641)
+    want_big, want_small = per.compute_blocking(bb), per.compute_blocking(bb[:small])
+    monkeypatch.delenv("NSG_COOP_TRUNK")
+    monkeypatch.setenv("NSG_COOP_FLAG_BASE", str((1 << 24) - 600))  # the fourth launch clears the array and starts at zero
+    ev, _ = make(nsg, 2, 256, big, precision="f16m6", seed=640)
+    for i in range(8):
+        n, want = (small, want_small) if i % 3 == 1 else (big, want_big)
+        got = ev.compute_blocking(bb[:n])
+        assert ev.last_launch_kind()[0] == "coop"
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+    assert ev.team_stats()["fallbacks"] == 0
+
+
 def test_cooperative_trunk_members_on_different_xcds_are_noticed(nsg, oracle, monkeypatch):
     """The cooperative trunk hands a board's rows from member to member through the L2 of ONE XCD (plain stores,
     L1-bypassing loads): every member publishes its XCC_ID with its flag and every poll compares it with the poller's own.
