@@ -1240,6 +1240,7 @@ static int checkTuningEnv() {
         {"NSG_TEAM_FAULT_LAUNCHES", 0, 1000000, "test hook: team launches made one workgroup short"},
         {"NSG_COOP_FAULT_XCC_LAUNCHES", 0, 1000000, "test hook: cooperative launches whose members claim different XCDs"},
         {"NSG_COOP_FLAG_BASE", 0, (1 << 24) - 1, "test hook: first flag value of the evaluator's first cooperative launch"},
+        {"NSG_HEADS_SMALL_BOARDS", 0, 65535, "largest batch whose heads run four one-fragment waves per workgroup (read once per process)"},
         {"NSG_TEAM_MEMBERS", 16, 96, "most workgroups per board of the team trunk on a 256-channel net: 16, 32, 48 or 96 "
                                      "(= 1, 2, 3 or 6 row groups; a 192-channel net runs 12 per row group)"}};
     for (const Var& v : vars) {
