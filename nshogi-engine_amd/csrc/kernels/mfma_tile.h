@@ -1559,29 +1559,33 @@ _Pragma("unroll") \
                                                         f16BitsToF32((uint16_t)(rp[2 + k][i] >> 16));
                             }
                     } else if constexpr (kM6) {
-                        // lo block -> 32 f16 (v_cvt_scalef32_pk32_f16_fp6 multiplies by the block scale); slots
-                        // 0..15 are the even lane group's channels, 16..31 the odd one's
+                        // lo block -> f16 (v_cvt_scalef32_pk32_f16_fp6 multiplies by the block scale).  The block's codes
+                        // 0..15 (three dwords) are the even lane group's channels, 16..31 (the other three) the odd one's:
+                        // a lane puts ITS three dwords first and takes the first sixteen values -- three selects on the
+                        // source instead of eight on the decoded halves
                         typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
                         typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
-                        const u32x6 blk = {rp[2].x, rp[2].y, rp[2].z, rp[2].w, rp[3].x, rp[3].y};
+                        const bool odd = (g & 1) != 0;
+                        const uint32_t c0 = odd ? rp[2].w : rp[2].x, c1 = odd ? rp[3].x : rp[2].y, c2 = odd ? rp[3].y : rp[2].z;
+                        const u32x6 blk = {c0, c1, c2, c0, c1, c2};
                         const float sc = __uint_as_float((rp[3].z & 0xffu) << 23);
                         u32x16 lh;
                         asm("v_cvt_scalef32_pk32_f16_fp6 %0, %1, %2" : "=&v"(lh) : "v"(blk), "v"(sc));
-                        const bool odd = (g & 1) != 0;
                         const uint32_t le[8] = {lh.s0, lh.s1, lh.s2, lh.s3, lh.s4, lh.s5, lh.s6, lh.s7};
-                        const uint32_t lo8[8] = {lh.s8, lh.s9, lh.sa, lh.sb, lh.sc, lh.sd, lh.se, lh.sf};
                         const uint32_t hh[8] = {rp[0].x, rp[0].y, rp[0].z, rp[0].w, rp[1].x, rp[1].y, rp[1].z, rp[1].w};
-                        // hi + lo in f32 as ONE v_fma_mix_f32 per value (both f16 operands converted on the
-                        // fly; the opaque 1.0 keeps the fma from being folded into convert + add + add)
-                        typedef _Float16 f16x2r __attribute__((ext_vector_type(2)));
+                        // hi + lo in f32 as ONE v_fma_mix_f32 per value (hi * 1.0 + lo, both f16 halves converted on the
+                        // fly: exact), added to the accumulator pair by one packed add
+                        typedef float f32x2r __attribute__((ext_vector_type(2)));
                         float one = 1.0f;
                         asm("" : "+v"(one));
 #pragma unroll
                         for (int d = 0; d < 8; ++d) { // dword d of my half = channels 2d, 2d+1
-                            const f16x2r l2 = __builtin_bit_cast(f16x2r, odd ? lo8[d] : le[d]);
-                            const f16x2r h2 = __builtin_bit_cast(f16x2r, hh[d]);
-                            v[2 * d] += __builtin_fmaf((float)h2[0], one, (float)l2[0]);
-                            v[2 * d + 1] += __builtin_fmaf((float)h2[1], one, (float)l2[1]);
+                            f32x2r rs;
+                            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(rs[0]) : "v"(hh[d]), "v"(one), "v"(le[d]));
+                            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(rs[1]) : "v"(hh[d]), "v"(one), "v"(le[d]));
+                            const f32x2r sum = f32x2r{v[2 * d], v[2 * d + 1]} + rs;
+                            v[2 * d] = sum[0];
+                            v[2 * d + 1] = sum[1];
                         }
                     } else if constexpr (kM8) {
                         constexpr float kLoInv = 1.0f / (float)(1 << kM8LoShift);
@@ -1656,28 +1660,35 @@ _Pragma("unroll") \
                         // 16-wide ext_vector in this loop compiled to compare/select chains, 2400 extra instructions)
                         typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                         uint32_t hpv[8], sa[8], sb[8];
-                        u16x2 mhp = {0, 0}, mlp = {0, 0}; // running maxima of |hi|, |lo| as f16 bit patterns (order-preserving)
+                        // running maxima of |x| and |x - hi| in f32, one v_max3_f32 with |.| modifiers per pair: rounding to
+                        // f16 is monotonic, so the f16 of the maximum IS the maximum of the f16 values the block stores
+                        // (masking the packed f16 pairs and taking packed integer maxima was four instructions per pair)
+                        float mh = 0.f, ml = 0.f;
                         float mone = -1.0f;
                         asm("" : "+v"(mone));
+                        (void)sizeof(u16x2);
 #pragma unroll
                         for (int d = 0; d < 8; ++d) {
                             const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * d], floorV, 65000.f),
                                              __builtin_amdgcn_fmed3f(v[2 * d + 1], floorV, 65000.f)};
                             const f16x2 h = __builtin_convertvector(x, f16x2);
-                            // lo = x - hi as one v_fma_mix_f32 per value (hi converted on the fly)
-                            const f32x2 lx = {__builtin_fmaf((float)h[0], mone, x[0]), __builtin_fmaf((float)h[1], mone, x[1])};
                             const uint32_t hp = __builtin_bit_cast(uint32_t, h);
+                            // lo = x - hi as ONE v_fma_mix_f32 per value: the f16 half of `hp` is converted on the fly (written
+                            // as (float)h[i] the compiler emitted a v_cvt_f32_f16 per value in front of a plain fma)
+                            f32x2 lx;
+                            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lx[0]) : "v"(hp), "v"(mone), "v"(x[0]));
+                            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lx[1]) : "v"(hp), "v"(mone), "v"(x[1]));
                             const uint32_t lp = __builtin_bit_cast(uint32_t, __builtin_convertvector(lx, f16x2));
                             hpv[d] = hp;
-                            const u16x2 ha = __builtin_bit_cast(u16x2, hp & 0x7fff7fffu), la = __builtin_bit_cast(u16x2, lp & 0x7fff7fffu);
-                            mhp = __builtin_elementwise_max(mhp, ha);
-                            mlp = __builtin_elementwise_max(mlp, la);
+                            mh = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x[0]), __builtin_fabsf(x[1])), mh);
+                            ml = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(lx[0]), __builtin_fabsf(lx[1])), ml);
                             const u32x2v sw = __builtin_amdgcn_permlane16_swap(hp, lp, false, false);
                             sa[d] = sw.x;
                             sb[d] = sw.y;
                         }
                         // f16 bit pattern -> E8M0: f16 exponent field e5 (bias 15) is the float exponent e5 + 112
-                        const uint32_t mhb = mhp[0] > mhp[1] ? mhp[0] : mhp[1], mlb = mlp[0] > mlp[1] ? mlp[0] : mlp[1];
+                        const uint32_t mbits = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{mh, ml}, f16x2));
+                        const uint32_t mhb = mbits & 0xffffu, mlb = mbits >> 16;
                         op[0] = u32x4{hpv[0], hpv[1], hpv[2], hpv[3]};
                         op[1] = u32x4{hpv[4], hpv[5], hpv[6], hpv[7]};
                         const u32x16 src = {sa[0], sa[1], sa[2], sa[3], sa[4], sa[5], sa[6], sa[7],
