@@ -751,8 +751,13 @@ nsg::ConvPlan planForBatch(nsg_evaluator* ev, int B) {
             // -- two, three or six row groups of three, two or one fragment: as many as fit the chip in one round
             const int k8max = ev->tuning.rowsplit8Max;
             if (k8max >= 0 ? B <= k8max : true) {
+                // (three row groups = twelve workgroups per board: three boards' do not fit an XCD, so 17-21 boards have
+                // no cooperative form with them; two row groups as ONE cooperative launch beat three as per-layer
+                // launches by 2...9 %: profiles/r04/zn_*.  Without the cooperative trunk -- switched off, the device's
+                // lock lost, after a give-up -- three row groups it is.)
+                const bool coop = ev->coopEnabled && ev->prec == nsg::kF16m6 && ev->teamStatusDev && ev->coopFlags.p;
                 if ((long)B * 24 <= cus) plan.msplit = 6;
-                else if ((long)B * 12 <= cus) plan.msplit = 3;
+                else if ((long)B * 12 <= cus && !coop) plan.msplit = 3;
                 else if ((long)B * 8 <= cus) plan.msplit = 2;
             }
         } else

@@ -210,7 +210,9 @@ def test_f16m8_k_split_tiles(nsg, oracle, monkeypatch, channels, batch, ksplit, 
     # the smallest batches split the rows of a four-way K split over two workgroups as well (eight per board)
     rows8 = ksplit == 4 and batch * 8 <= cus
     assert plan["trunk_precision"] == mx and plan["boards_per_group"] == 1 and plan["k_split"] == ksplit
-    assert plan["row_split"] == (6 if batch * 24 <= cus else 3 if batch * 12 <= cus else 2 if rows8 else 1)
+    # (an f16m6 evaluator takes two row groups where three would fit: twelve workgroups per board have no cooperative form)
+    three = batch * 12 <= cus and not (mx == "f16m6" and ev.last_launch_kind()[0] == "coop")
+    assert plan["row_split"] == (6 if batch * 24 <= cus else 3 if three else 2 if rows8 else 1)
     idx = sorted({0, batch // 2, batch - 1})
     check((p[idx], v[idx], d[idx]), oracle.net(blob).evaluate(bb[idx]), TOL)
     x3, _ = make(nsg, 3, channels, bmax, precision="f16x3", seed=63)
@@ -1189,7 +1191,10 @@ def test_cooperative_trunk_mid_batches(nsg, oracle, monkeypatch, channels, batch
     monkeypatch.setenv("NSG_COOP_TRUNK", "0")
     per, _ = make(nsg, 3, channels, batch, precision="f16m6", seed=610)
     pp, vp, dp = per.compute_blocking(bb)
-    assert per.last_launch_kind() == ("per_layer", 0) and per.last_plan() == ev.last_plan()
+    # (the same plan, but for 17-21 boards of a 256-channel net: three row groups per layer, two as one launch -- row groups
+    # do not change a bit of the result)
+    same = {k: v for k, v in per.last_plan().items() if k != "row_split"} == {k: v for k, v in ev.last_plan().items() if k != "row_split"}
+    assert per.last_launch_kind() == ("per_layer", 0) and same, (per.last_plan(), ev.last_plan())
     np.testing.assert_array_equal(pp, p)
     np.testing.assert_array_equal(vp, v)
     np.testing.assert_array_equal(dp, d)
