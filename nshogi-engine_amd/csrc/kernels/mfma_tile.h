@@ -74,6 +74,11 @@ constexpr bool kCoopSameXcd = false;
 #else
 constexpr bool kCoopSameXcd = true;
 #endif
+#ifdef NSG_COOP_NO_KEEP // A/B partner build: every chunk of every layer's input through global memory
+constexpr bool kCoopKeepOwnSlice = false;
+#else
+constexpr bool kCoopKeepOwnSlice = true;
+#endif
 
 // SIZE = boards per workgroup (kConv) or 16-row fragments per workgroup.
 template <int MODE, int SIZE, int NWAVES, int NBUF = 2>
@@ -490,8 +495,15 @@ struct StepSeq {
 // of activations (input tiles, residual) is an agent-scope (sc1) buffer load that never hits this CU's L1; every output
 // store is a plain store that stays in the XCD's L2 (kCoopSameXcd: the members of a board share an XCD, verified at run
 // time) or, in the -DNSG_COOP_SC1_STORES build, a write-through (sc1) store.
-template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1, int SS = 1, int PART = 0, bool COOP = false>
-__device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds) {
+// KEEP (cooperative trunk, one row group per board): the epilogue builds this workgroup's output rows -- its 64- or
+// 128-channel slice of the board -- straight in the NEXT layer's LDS image (the chunk buffers of its own channels: the
+// image is the staging area of the row-major move to global memory as well), and the next layer, told so by `haveOwn`,
+// neither requests nor stages those chunks: half the tile of a two-way K split, a quarter of a four-way one, never
+// leaves the CU.
+template <int PREC, int MODE, int SIZE, int NFRAG, int NWAVES, int RES, int MS = 1, int KS = 1, int SS = 1, int PART = 0, bool COOP = false,
+          bool KEEP = false>
+__device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, bool zeroLds, bool haveOwn = false) {
+    static_assert(!KEEP || (COOP && SIZE == 1 && MS == 1 && KS > 1 && PREC == kF16m6), "own slice kept in LDS: cooperative K-split tiles");
     static_assert(!COOP || (isMx(PREC) && MODE == kConv && NFRAG == 4), "cooperative trunk: MX conv tiles");
     static_assert(SS == 1 || (isMx(PREC) && MODE == kConv && SIZE == 2 && MS == 1 && KS == 1 && NWAVES % SS == 0 && PART < SS),
                   "slab split: two-board MX conv tiles");
@@ -609,16 +621,21 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     };
     constexpr bool kResident = isMx(PREC) && KS > 1;
     constexpr int kResChunks = 8;
+    // KEEP: the chunks of this workgroup's own output channels (its NWAVES / KS channel groups of 64 = two chunks each)
+    constexpr int kOwnChunks = KEEP ? 2 * (NWAVES / KS) : 0;
+    [[maybe_unused]] const int ownChunk0 = (int)blockIdx.y * kOwnChunks;
     u32x4 stAll[kResident ? kResChunks : 1][G::kItems];
     if constexpr (kResident) {
         // (a chunk the layer does not have -- the stem's, a 192-channel layer's last two -- is requested past the end of
         // the descriptor and comes back as zeros: one select on the lane offset instead of a branch around every load)
 #pragma unroll
-        for (int c = 0; c < kResChunks; ++c)
+        for (int c = 0; c < kResChunks; ++c) {
+            if (KEEP && haveOwn && c >= ownChunk0 && c < ownChunk0 + kOwnChunks) continue; // (wave-uniform: already in LDS)
 #pragma unroll
             for (int k = 0; k < G::kItems; ++k)
                 stAll[c][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     xrs, c < nkc ? srcRel[k] : 0x7ffffff0, c * 128, COOP ? 16 /* sc1 */ : 0));
+        }
         __builtin_amdgcn_sched_barrier(0);
         NSG_STAMP(4); // (diagnostic builds) every tile load issued
     }
@@ -821,10 +838,12 @@ _Pragma("unroll") \
             __syncthreads();
             NSG_STAMP(5); // image cleared; what follows waits for the tile loads
 #pragma unroll
-            for (int c = 0; c < kChunks; ++c)
+            for (int c = 0; c < kChunks; ++c) {
+                if (KEEP && haveOwn && c >= ownChunk0 && c < ownChunk0 + kOwnChunks) continue; // (the epilogue before this layer left them here)
 #pragma unroll
                 for (int k = 0; k < G::kItems; ++k)
                     if (__builtin_expect(c < nkc, 1)) stageStore(smem + (itemOk[k] ? c * G::kBuf : 0) + dstOff[k], stAll[c][k]);
+            }
             __syncthreads();
         }
         NSG_STAMP(1);
@@ -1496,6 +1515,32 @@ _Pragma("unroll") \
         // executes a wave's operations in order, so two staging regions suffice: the reads of
         // fragment i-1 are issued before R(i+1) overwrites their region.
         static_assert(kRegions >= 2, "the pipelined epilogue needs two staging regions per wave");
+        // Where row `row_` of fragment f, 16-byte piece `piece_` of this wave's row slice, is staged.  KEEP: in the next
+        // layer's image -- chunk buffer 2 * waveGroup + piece / 8, plane piece % 8, the row's entry (every fragment has
+        // its own rows: no region is reused); a row past the board goes to the lane's trash slot (it is never stored,
+        // and must not touch the halo row its entry formula would hit).
+        [[maybe_unused]] int entLi[KEEP ? kMFe : 1], entLL[KEEP ? kMFe : 1][kIPF];
+        if constexpr (KEEP) {
+            static_assert(kRowB == 256 && kIPF == 4, "image staging: 256-byte row slices");
+            const int slice_ = waveGroup * 2 * G::kBuf;
+            // (entryOfRow for m < 128: 24 + (y + 1) * 10 + x = 34 + m + m / 9; -1: a padding row)
+            auto entryByte = [&](int m_) { return m_ < G::kRows ? slice_ + (34 + m_ + ((m_ * 57) >> 9)) * 16 : -1; };
+#pragma unroll
+            for (int f = 0; f < kMFe; ++f) {
+                entLi[f] = entryByte((fBaseE + f) * 16 + li);
+#pragma unroll
+                for (int it = 0; it < kIPF; ++it) entLL[f][it] = entryByte((fBaseE + f) * 16 + it * kRPI + lrow);
+            }
+        }
+        auto stageAt = [&](int f, int rowIsLi, int it, int piece_) -> unsigned char* { // row = li (MFMA layout) or it * kRPI + lrow
+            if constexpr (KEEP) {
+                const int e_ = rowIsLi ? entLi[f] : entLL[f][it];
+                // (a padding row: every piece to the lane's own trash slot)
+                return smem + (e_ < 0 ? G::kLds + lane * 16 : e_ + (piece_ >> 3) * G::kBuf + (piece_ & 7) * G::kPlaneStride);
+            } else {
+                return ebuf + (f % kRegions) * kFragBytes + (rowIsLi ? li : it * kRPI + lrow) * kRowS + piece_ * 16;
+            }
+        };
         u32x4 rpp[2][kNP];
         u32x4 tt[kIPF];
 #pragma unroll
@@ -1507,7 +1552,7 @@ _Pragma("unroll") \
                 const int f = i - 1;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it)
-                    tt[it] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + (it * kRPI + lrow) * kRowS + lpc * 16);
+                    tt[it] = *reinterpret_cast<const u32x4*>(stageAt(f, 0, it, lpc));
                 roS = rowOffs(f);
             }
             if (hasRes && i + 1 < kMFe) { // ---- R(i+1)
@@ -1516,7 +1561,6 @@ _Pragma("unroll") \
                 const u32x4 ro = roR;
 #pragma unroll
                 for (int it = 0; it < kIPF; ++it) {
-                    const int r = it * kRPI + lrow;
                     u32x4 t = u32x4{0u, 0u, 0u, 0u};
                     if (f < kPreFrags) {
                         t = rpre[f < kPreFrags ? f : 0][it];
@@ -1524,13 +1568,13 @@ _Pragma("unroll") \
                         if (__builtin_expect(rowOk(f, it, ro), 1))
                             t = resLoad(rowByte(f, it, ro));
                     }
-                    *reinterpret_cast<u32x4*>(ebuf + (f % kRegions) * kFragBytes + r * kRowS + lpc * 16) = t;
+                    *reinterpret_cast<u32x4*>(stageAt(f, 0, it, lpc)) = t;
                 }
 #pragma unroll
                 for (int k = 0; k < kNP; ++k) {
                     // (kF16m6: both lanes of a chunk read the chunk's whole lo block, pieces 2 and 3)
                     const int po = (kM6 && k >= 2) ? (g >> 1) * 128 + 96 + (k - 2) * 16 : pieceOff(k);
-                    rpp[f & 1][k] = *reinterpret_cast<const u32x4*>(ebuf + (f % kRegions) * kFragBytes + li * kRowS + po);
+                    rpp[f & 1][k] = *reinterpret_cast<const u32x4*>(stageAt(f, 1, 0, po / 16));
                 }
             }
             if (i >= 0 && i < kMFe) { // ---- X(i)
@@ -1540,7 +1584,7 @@ _Pragma("unroll") \
                 for (int j = 0; j < NFRAG; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaf(acc[f][j][r], A.accScale, bv[j * 4 + r]);
-                unsigned char* lrowp = ebuf + (f % kRegions) * kFragBytes + li * kRowS;
+                [[maybe_unused]] unsigned char* lrowp = ebuf + (f % kRegions) * kFragBytes + li * kRowS;
                 if (hasRes) {
                     const u32x4* rp = rpp[f & 1];
                     if constexpr (PREC == kFp32) {
@@ -1736,7 +1780,10 @@ _Pragma("unroll") \
                         for (int i = 0; i < 4; ++i) op[k][i] = packPair<PREC>(v[k * 8 + 2 * i], v[k * 8 + 2 * i + 1]);
                 }
 #pragma unroll
-                for (int k = 0; k < kNP; ++k) *reinterpret_cast<u32x4*>(lrowp + (__builtin_expect(outX3, false) ? pieceOffX3(k) : pieceOff(k))) = op[k];
+                for (int k = 0; k < kNP; ++k) {
+                    if constexpr (KEEP) *reinterpret_cast<u32x4*>(stageAt(f, 1, 0, (__builtin_expect(outX3, false) ? pieceOffX3(k) : pieceOff(k)) / 16)) = op[k];
+                    else *reinterpret_cast<u32x4*>(lrowp + (__builtin_expect(outX3, false) ? pieceOffX3(k) : pieceOff(k))) = op[k];
+                }
             }
             if (i >= 1) { // ---- S(i-1), stores: kRPI rows x kRowB contiguous bytes per instruction
                 const int f = i - 1;
@@ -1932,8 +1979,10 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void coopTrunkKernel(const Args* __
             __syncthreads(); // the other waves load behind the polling wave's match
             if (*gaveUp) return;
         }
-        if (A.res) tileBody<PREC, kConv, 1, NFRAG, NWAVES, 1, MS, KS, 1, 0, true>(A, smem, true);
-        else tileBody<PREC, kConv, 1, NFRAG, NWAVES, 0, MS, KS, 1, 0, true>(A, smem, true);
+        // (one row group per board: the workgroup's own channels of the layer before are in its LDS already -- tileBody, KEEP)
+        constexpr bool kKeep = kCoopKeepOwnSlice && MS == 1;
+        if (A.res) tileBody<PREC, kConv, 1, NFRAG, NWAVES, 1, MS, KS, 1, 0, true, kKeep>(A, smem, true, l > 0);
+        else tileBody<PREC, kConv, 1, NFRAG, NWAVES, 0, MS, KS, 1, 0, true, kKeep>(A, smem, true, l > 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its write-through stores have left
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(mine + me, (flagBase + (unsigned)(l + 1)) | (xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
