@@ -333,22 +333,32 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 //   0..5  interior squares (y, x in 1..7), 96 of the 98        all nine taps
 //   6     top rows, x = 1..8 of both boards                    no dy = -1 taps
 //   7     bottom rows, x = 0..7                                no dy = +1 taps
-//   8     left columns y = 1..7 + the corners (0,0)            no dx = -1 taps
+//   8     left columns y = 1..7 + the last 2 interior squares  all nine taps
 //   9     right columns y = 1..7 + the corners (8,8)           no dx = +1 taps
-//   10    the last 2 interior squares (+ 14 padding rows)      all nine taps
-// 99 -> 87 (fragment, tap) pairs per chunk: 12 % fewer matrix instructions and fragment reads.
-struct EdgeRows {
+//   10    the corners (0,0) (+ 14 padding rows)                the four taps dy >= 0, dx >= 0
+// 99 -> 85 (fragment, tap) pairs per chunk: 14 % fewer matrix instructions and fragment reads.  (Round 4: the fragment
+// that exists for two rows only used to hold the two interior squares that fit nowhere else -- nine taps for two
+// rows; it now holds two corners, four taps, and the interior squares take the corners' places among the left columns,
+// whose fragment then runs every tap: 87 -> 85.)
+// (CORNERS = false: round 3's assignment -- corners (0,0) in fragment 8, no dx = -1 taps there, the two left-over
+// interior squares in fragment 10 with all nine taps, 87 pairs -- which the opt-in slab-split tiles keep: their waves'
+// static shares of a chunk pair were balanced for it.)
+template <bool CORNERS>
+struct EdgeRowsT {
     static constexpr int kMF = 11;
     static constexpr bool needTap(int f, int t) {
-        return f == 6 ? t / 3 != 0 : f == 7 ? t / 3 != 2 : f == 8 ? t % 3 != 0 : f == 9 ? t % 3 != 2 : true;
+        if (!CORNERS) return f == 6 ? t / 3 != 0 : f == 7 ? t / 3 != 2 : f == 8 ? t % 3 != 0 : f == 9 ? t % 3 != 2 : true;
+        return f == 6 ? t / 3 != 0 : f == 7 ? t / 3 != 2 : f == 9 ? t % 3 != 2 : f == 10 ? (t / 3 != 0 && t % 3 != 0) : true;
     }
     // board, rank and file of row r of fragment f; false = padding row
     static constexpr __host__ __device__ bool square(int f, int r, int& b, int& y, int& x) {
         b = r >> 3;
         const int k = r & 7;
-        if (f < 6 || f == 10) {
-            if (f == 10 && r >= 2) return false;
-            const int i = (f < 6 ? f * 16 : 96) + r;
+        if (f == 10 && r >= 2) return false;
+        if (CORNERS ? f == 10 : (f == 8 && k == 7)) { // the two (0, 0) corners
+            b = CORNERS ? r : r >> 3; y = 0; x = 0;
+        } else if (f < 6 || (CORNERS ? (f == 8 && k == 7) : f == 10)) { // (... the two interior squares left over)
+            const int i = f < 6 ? f * 16 + r : 96 + (CORNERS ? (r >> 3) : r);
             b = i >= 49 ? 1 : 0;
             const int j = i - b * 49;
             const int q = (j * 37) >> 8; // j / 7 for j < 49
@@ -359,7 +369,7 @@ struct EdgeRows {
         } else if (f == 7) {
             y = 8; x = k;
         } else if (f == 8) {
-            y = k < 7 ? 1 + k : 0; x = 0;
+            y = 1 + k; x = 0;
         } else {
             y = k < 7 ? 1 + k : 8; x = 8;
         }
@@ -440,14 +450,14 @@ struct OwnSeq {
 // The (own slab, fragment) steps of one chunk pair in issue order, and their inverse: with edge-packed rows
 // the steps whose tap a fragment does not need are left out; the sequence is padded with null steps to a
 // multiple of the fragment window (the window slot of a step must be the same in every pair).
-template <class OS, int MF, bool PERM, int WIN>
+template <class OS, int MF, bool PERM, int WIN, class ER>
 struct StepSeq {
     static constexpr int kMax = (27 * MF + WIN - 1) / WIN * WIN;
     struct Tab {
         int n, padded;
         short pos[kMax], frag[kMax], index[27 * MF], xord[kMax];
     };
-    static constexpr bool active(int u, int f) { return !PERM || EdgeRows::needTap(f, OS::slab(u) / 3); }
+    static constexpr bool active(int u, int f) { return !PERM || ER::needTap(f, OS::slab(u) / 3); }
     static constexpr Tab make() {
         Tab t{};
         int n = 0;
@@ -533,6 +543,7 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #else
     constexpr bool kPerm = isMx(PREC) && MODE == kConv && SIZE == 2 && MS == 1 && KS == 1;
 #endif
+    using EdgeRows = EdgeRowsT<SS == 1>;
     static_assert(!kPerm || kMFw == EdgeRows::kMF, "edge-packed rows: eleven fragments");
 
     int tidOpaque = threadIdx.x;
@@ -726,7 +737,7 @@ _Pragma("unroll") \
 #else
         constexpr bool kSpread = kMFw > NFRAG; // (fragments 0 .. NFRAG run every tap, edge-packed rows or not)
 #endif
-        using ST = StepSeq<OS, kMFw, kPerm, kWin>;
+        using ST = StepSeq<OS, kMFw, kPerm, kWin, EdgeRows>;
         constexpr int kReal = ST::kReal;   // (own slab, fragment) steps that issue MFMAs
         constexpr int kSteps = ST::kSteps; // ... padded to a multiple of the window: a step's slot is the same in every pair
         constexpr int kPad = kSteps - kReal;
