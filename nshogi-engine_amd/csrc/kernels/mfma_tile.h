@@ -79,6 +79,11 @@ constexpr bool kCoopKeepOwnSlice = false;
 #else
 constexpr bool kCoopKeepOwnSlice = true;
 #endif
+#ifdef NSG_NO_EDGE_ROWS_ONE_BOARD // A/B partner build: one-board MX tiles in natural row order, all taps
+constexpr bool kEdgeRowsOneBoard = false;
+#else
+constexpr bool kEdgeRowsOneBoard = true;
+#endif
 
 // SIZE = boards per workgroup (kConv) or 16-row fragments per workgroup.
 template <int MODE, int SIZE, int NWAVES, int NBUF = 2>
@@ -382,6 +387,38 @@ struct EdgeRowsT {
     }
 };
 
+// The same for ONE board (the one-board persistent tiles of 144 ... 256 boards): 81
+// squares in six fragments.  Fragments 0-2: 48 interior squares; 3: the left and right columns (y = 1..7) + the last
+// interior square -- all nine taps, and with the first three what every slab starts with (the loop spreads a slab's
+// record requests over its first four steps: those four fragments run every tap); 4: the top row with its two corners,
+// no dy = -1 taps; 5: the bottom row with its corners, no dy = +1 taps.  54 -> 48 (fragment, tap) pairs per chunk: 11 %
+// fewer matrix instructions and fragment reads.
+struct EdgeRows1 {
+    static constexpr int kMF = 6;
+    static constexpr bool needTap(int f, int t) { return f == 4 ? t / 3 != 0 : f == 5 ? t / 3 != 2 : true; }
+    static constexpr __host__ __device__ bool square(int f, int r, int& b, int& y, int& x) {
+        b = 0;
+        if (f < 3 || (f == 3 && r == 14)) { // interior square i
+            const int i = f < 3 ? f * 16 + r : 48;
+            const int q = (i * 37) >> 8; // i / 7 for i < 49
+            y = 1 + q;
+            x = 1 + i - q * 7;
+            return true;
+        }
+        if (f == 3) { // left column, right column
+            if (r > 14) return false;
+            y = 1 + (r < 7 ? r : r - 7);
+            x = r < 7 ? 0 : 8;
+            return true;
+        }
+        // top (f == 4) / bottom row: x = 0..8
+        if (r > 8) return false;
+        y = f == 4 ? 0 : 8;
+        x = r;
+        return true;
+    }
+};
+
 // "Slab split" (SS waves per 64-channel group, two-board MX tiles at mid batches): the SS waves of a channel
 // group share the K range of every chunk pair by SLABS -- each runs its own static subset of the pair's 27
 // slabs (18 f16 main slabs M0..M17 = (tap, chunk A|B), 9 MX slabs X0..X8) for ALL row fragments and the
@@ -541,10 +578,13 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
 #ifdef NSG_NO_EDGE_ROWS // A/B partner build (make ab ABFLAGS=-DNSG_NO_EDGE_ROWS): natural row order, all taps
     constexpr bool kPerm = false;
 #else
-    constexpr bool kPerm = isMx(PREC) && MODE == kConv && SIZE == 2 && MS == 1 && KS == 1;
+    // (one board: the tiles that stage their chunks, KS == 1 -- the persistent tiles of 144 ... 256 boards: +3...3.7 %.  On
+    // the K-split tiles the table-driven epilogue of a wave's two or three fragments costs more than the skipped taps
+    // save: -0.6...-2 % at 33-128 boards, profiles/r04/zz_*; the code paths are there, `&& KS == 1` is the switch.)
+    constexpr bool kPerm = isMx(PREC) && MODE == kConv && NFRAG == 4 && MS == 1 && KS == 1 && (SIZE == 2 || (SIZE == 1 && kEdgeRowsOneBoard));
 #endif
-    using EdgeRows = EdgeRowsT<SS == 1>;
-    static_assert(!kPerm || kMFw == EdgeRows::kMF, "edge-packed rows: eleven fragments");
+    using EdgeRows = std::conditional_t<SIZE == 1, EdgeRows1, EdgeRowsT<SS == 1>>;
+    static_assert(!kPerm || kMFw == EdgeRows::kMF, "edge-packed rows: one table row per fragment");
 
     int tidOpaque = threadIdx.x;
     // (opaque to the optimiser: inside the persistent trunk kernel the per-lane address tables
@@ -670,6 +710,9 @@ __device__ __forceinline__ void tileBody(const Args& A, unsigned char* smem, boo
     // the epilogue moves a fragment's 16 rows to and from global memory, and they are no longer consecutive
     // there -- byte offset of row r = it*4 + lrow of fragment f inside the tile at [(f*4 + lrow)*4 + it],
     // ~0 = padding row, written by the sixteen lanes that have just computed the natural row of (f, li))
+    constexpr int kTabParts = KS > 1 ? KS : SS;
+    constexpr int kTabFrags = (kMFw + kTabParts - 1) / kTabParts * kTabParts; // fragments the epilogue may ask the table about
+    static_assert(!kPerm || (kTabFrags + 1) * 64 <= 1024, "epilogue row table");
 #define NSG_COMPUTE_ABASE \
 _Pragma("unroll") \
     for (int f = 0; f < kMFw; ++f) { \
@@ -682,7 +725,11 @@ _Pragma("unroll") \
             if (wave == 0 && g == 0) { \
                 reinterpret_cast<unsigned*>(smem + G::kRowTabOff)[(f * 4 + (li & 3)) * 4 + (li >> 2)] = \
                     m >= 0 ? (unsigned)m * (unsigned)(A.cout * ES) : ~0u; \
-                if (f == kMFw - 1) reinterpret_cast<unsigned*>(smem + G::kRowTabOff)[(kMFw * 4 + (li & 3)) * 4 + (li >> 2)] = ~0u; \
+                /* (fragments past the tile's last: the K or slab parts' shares of a count that does not divide) */ \
+                if (f == kMFw - 1) { \
+                    _Pragma("unroll") for (int fx = kMFw; fx <= kTabFrags; ++fx) \
+                        reinterpret_cast<unsigned*>(smem + G::kRowTabOff)[(fx * 4 + (li & 3)) * 4 + (li >> 2)] = ~0u; \
+                } \
             } \
         } \
         if constexpr (G::kBoards) { \
@@ -845,6 +892,7 @@ _Pragma("unroll") \
         } else {
             // every chunk of the board (at most eight) was requested at the top of the kernel
             constexpr int kChunks = kResChunks;
+            if constexpr (kPerm) { NSG_COMPUTE_ABASE }
             if (zeroLds) zeroHalo<G, kShiftLo>(smem, tid);
             __syncthreads();
             NSG_STAMP(5); // image cleared; what follows waits for the tile loads
@@ -942,7 +990,10 @@ _Pragma("unroll") \
                     // NFRAG steps (a vector-memory instruction occupies the wave's issue port longer than the half of an
                     // MFMA's cycles that are free: four to eight of them behind ONE MFMA hold the next MFMA back; one
                     // or two per step hide behind that step's own MFMAs) and the tile items in the step behind them.
-                    const int fTile = kSpread ? NFRAG : 0;
+                    // (the step that carries a slab's tile requests must exist in every slab: with one board's edge-packed
+                    // rows only fragments 0 .. 3 run every tap -- the requests share fragment 3's step with its records)
+                    const int fTile = kSpread ? (kPerm && SIZE == 1 ? NFRAG - 1 : NFRAG) : 0;
+                    static_assert(!kPerm || SIZE != 1 || (ST::active(0, NFRAG - 1) && ST::active(8, NFRAG - 1)), "tile-request step");
                     if (kSpread ? f < NFRAG : f == 0) {
                         if (!Q::isX(s)) { // f16 record two own main slabs ahead (beyond this pair: the next pair's)
                             const int o2 = OS::mainOrd(u) + 2;
@@ -1481,21 +1532,20 @@ _Pragma("unroll") \
         };
         // edge-packed rows: per-lane offsets of the four rows (it = 0..3) this lane moves for fragment f
         [[maybe_unused]] const unsigned permLane = (unsigned)lpc * 16u;
-        constexpr int kFBasePerm = PART * kMFe; // (edge-packed tiles have no K split: the first fragment is static)
+        const int fBasePerm = (KS > 1) ? (wave % KS) * kMFe : PART * kMFe; // this wave's first fragment in the workgroup's row table
         auto rowOffs = [&](int f) -> u32x4 {
-            if constexpr (kPerm) return *reinterpret_cast<const u32x4*>(smem + G::kRowTabOff + ((kFBasePerm + f) * 4 + lrow) * 16);
+            if constexpr (kPerm) return *reinterpret_cast<const u32x4*>(smem + G::kRowTabOff + ((fBasePerm + f) * 4 + lrow) * 16);
             else return u32x4{0u, 0u, 0u, 0u};
         };
         // (ok, byte offset from resBase / yBase) of row it*kRPI + lrow of fragment f
         auto rowOk = [&](int f, int it, const u32x4& ro) -> bool {
-            if constexpr (kPerm) return kFBasePerm + f < EdgeRows::kMF - 1 || ro[it] != ~0u; // only the last fragment (and what lies past the tile) has padding rows
+            if constexpr (kPerm) return (SIZE == 2 && KS == 1 && PART * kMFe + f < EdgeRows::kMF - 1) || ro[it] != ~0u; // (two boards: only the last fragment, and what lies past the tile, has padding rows)
             else return (fBaseE + f) * 16 + it * kRPI + lrow < rowLimit;
         };
         auto rowByte = [&](int f, int it, const u32x4& ro) -> size_t {
             if constexpr (kPerm) return (size_t)(ro[it] + permLane);
             else return (size_t)(f * 16 + it * kRPI) * rowBytes + laneOff;
         };
-        static_assert(!kPerm || KS == 1, "edge-packed rows: no K split");
 
         // Most of this wave's residual slice is requested up front (the main loop's operand registers
         // are dead), so the fragment pipeline below does not wait a global round trip per fragment.
@@ -1536,11 +1586,22 @@ _Pragma("unroll") \
             const int slice_ = waveGroup * 2 * G::kBuf;
             // (entryOfRow for m < 128: 24 + (y + 1) * 10 + x = 34 + m + m / 9; -1: a padding row)
             auto entryByte = [&](int m_) { return m_ < G::kRows ? slice_ + (34 + m_ + ((m_ * 57) >> 9)) * 16 : -1; };
+            // board row of row r_ of the workgroup's fragment fg_ (edge-packed rows: by the table's formula; a row or a
+            // fragment the tile does not have: past the board)
+            auto rowOfFrag = [&](int fg_, int r_) -> int {
+                if constexpr (kPerm) {
+                    int b_ = 0, y_ = 0, x_ = 0;
+                    const bool ok_ = EdgeRows::square(fg_ < EdgeRows::kMF ? fg_ : 0, r_, b_, y_, x_) && fg_ < EdgeRows::kMF;
+                    return ok_ ? y_ * 9 + x_ : G::kRows;
+                } else {
+                    return fg_ * 16 + r_;
+                }
+            };
 #pragma unroll
             for (int f = 0; f < kMFe; ++f) {
-                entLi[f] = entryByte((fBaseE + f) * 16 + li);
+                entLi[f] = entryByte(rowOfFrag(fBaseE + f, li));
 #pragma unroll
-                for (int it = 0; it < kIPF; ++it) entLL[f][it] = entryByte((fBaseE + f) * 16 + it * kRPI + lrow);
+                for (int it = 0; it < kIPF; ++it) entLL[f][it] = entryByte(rowOfFrag(fBaseE + f, it * kRPI + lrow));
             }
         }
         auto stageAt = [&](int f, int rowIsLi, int it, int piece_) -> unsigned char* { // row = li (MFMA layout) or it * kRPI + lrow
